@@ -1,0 +1,308 @@
+"""Generate golden vectors by running the REFERENCE's own hydra3.py / embedding.py on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference source
+never leaves that directory: what is written here is data only -- weights, inputs,
+outputs and gradients as .npz arrays plus a JSON list of state_dict keys/shapes.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz, *.json
+
+The absent sibling module `dataset2` (imported by the reference for two names that
+the hot path never calls) is stubbed before import.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+REF = os.environ.get("HYDRA_REFERENCE_DIR", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+sys.dont_write_bytecode = True
+_stub = types.ModuleType("dataset2")
+_stub.save_emb = lambda *a, **k: None
+_stub.MyDataset = type("MyDataset", (), {})
+sys.modules["dataset2"] = _stub
+sys.path.insert(0, REF)
+import embedding as ref_emb  # noqa: E402
+import hydra3 as ref  # noqa: E402
+
+FEAT_TYPES = {k: [] for k in ("user_sparse", "item_sparse", "user_array", "item_array",
+                              "user_continual", "item_continual", "item_emb")}
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def make_args(d, L, heads=2, blocks=2, dropout=0.2):
+    a = Namespace(device="cpu", hydra_hidden_units=d, hstu_hidden_units=d, hydra_num_heads=heads,
+                  hydra_num_blocks=blocks, hydra_dropout_rate=dropout, maxlen=L - 1, norm_first=False,
+                  num_actions=5, time_span=512)
+    ref_emb.SharedEmbeddingConfig(a)
+    return a
+
+
+def xavier_(module):
+    for p in module.parameters():
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+        else:                      # make biases / scales / D non-trivial so they are actually tested
+            p.data.add_(0.1 * torch.randn_like(p))
+
+
+def put(store, prefix, **arrays):
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        store[f"{prefix}/{k}"] = np.asarray(v)
+
+
+def put_params(store, prefix, module):
+    for k, v in module.state_dict().items():
+        store[f"{prefix}/param/{k}"] = v.detach().cpu().numpy()
+
+
+def g1_pscan(store):
+    for L in (1, 2, 3, 10, 25, 64, 100, 101, 512):
+        torch.manual_seed(100 + L)
+        B, ED, N = (2, 3, 4) if L < 512 else (1, 2, 2)
+        A = torch.rand(B, L, ED, N).mul_(0.9).add_(0.05).requires_grad_()
+        X = torch.randn(B, L, ED, N, requires_grad=True)
+        G = torch.randn(B, L, ED, N)
+        H = ref.pscan(A, X)
+        H.backward(G)
+        put(store, f"G1_pscan_L{L}", A=A, X=X, G=G, H=H, dA=A.grad, dX=X.grad)
+
+
+def g2_selective_scan(store):
+    for name, (B, L, ED, N) in {"a": (2, 7, 6, 4), "b": (3, 33, 8, 16)}.items():
+        torch.manual_seed(200 + L)
+        x = torch.randn(B, L, ED, requires_grad=True)
+        delta = torch.rand(B, L, ED).add_(0.01).requires_grad_()
+        A = (-torch.rand(ED, N) * 3).requires_grad_()
+        Bm = torch.randn(B, L, N, requires_grad=True)
+        C = torch.randn(B, L, N, requires_grad=True)
+        D = torch.randn(ED, requires_grad=True)
+        G = torch.randn(B, L, ED)
+        y = ref.selective_scan(x, delta, A, Bm, C, D)
+        y.backward(G)
+        put(store, f"G2_sscan_{name}", x=x, delta=delta, A=A, B=Bm, C=C, D=D, G=G, y=y,
+            dx=x.grad, ddelta=delta.grad, dA=A.grad, dB=Bm.grad, dC=C.grad, dD=D.grad)
+
+
+def g3_rmsnorm(store):
+    torch.manual_seed(300)
+    m = ref.RMSNorm(16)
+    m.scale.data = torch.randn(16)
+    x = torch.randn(3, 5, 16, requires_grad=True)
+    x.data[1, 2] = 0.0                                   # an all-zero row (padded position)
+    G = torch.randn(3, 5, 16)
+    y = m(x)
+    y.backward(G)
+    put(store, "G3_rmsnorm", x=x, scale=m.scale, G=G, y=y, dx=x.grad, dscale=m.scale.grad)
+
+
+def module_case(store, prefix, module, inputs, grad_inputs=(0,)):
+    """Run module(*inputs) in eval mode, record outputs and grads wrt inputs[i] and all params."""
+    module.eval()
+    ins = [t.clone().requires_grad_(i in grad_inputs) if torch.is_floating_point(t) else t
+           for i, t in enumerate(inputs)]
+    y = module(*ins)
+    G = torch.randn_like(y)
+    y.backward(G)
+    put_params(store, prefix, module)
+    put(store, prefix, y=y, G=G)
+    for i, t in enumerate(ins):
+        put(store, prefix, **{f"in{i}": t})
+        if torch.is_floating_point(t) and t.grad is not None:
+            put(store, prefix, **{f"din{i}": t.grad})
+    for k, p in module.named_parameters():
+        if p.grad is not None:
+            store[f"{prefix}/grad/{k}"] = p.grad.detach().numpy()
+
+
+def g4_mamba(store):
+    for hd, L, B in ((8, 9, 2), (32, 21, 2)):
+        torch.manual_seed(400 + hd)
+        m = ref.MambaBlock(hd, 16, 4 * hd, 16)
+        xavier_(m)
+        module_case(store, f"G4_mamba_hd{hd}", m, [torch.randn(B, L, hd)])
+
+
+def pad_mask(B, L, pads):
+    m = torch.ones(B, L, 1)
+    for b, p in enumerate(pads):
+        m[b, :p] = 0
+    return m
+
+
+def g5_mhm(store):
+    torch.manual_seed(500)
+    a = make_args(16, 12)
+    m = ref.MultiHeadMamba(16, 16, 64, 16, a)
+    xavier_(m)
+    x, xo = torch.randn(3, 12, 16), torch.randn(3, 12, 16)
+    module_case(store, "G5_mhm", m, [x, xo, pad_mask(3, 12, (0, 4, 11))], grad_inputs=(0, 1))
+
+
+def g6_blocks(store):
+    for name, cls in (("first", ref.HydraBlockFirst), ("regular", ref.HydraBlock)):
+        torch.manual_seed(600 + len(name))
+        a = make_args(16, 14)
+        m = cls(16, 16, 64, 16, a)
+        xavier_(m)
+        pm = pad_mask(3, 14, (0, 5, 13))
+        module_case(store, f"G6_block_{name}", m, [torch.randn(3, 14, 16) * pm, pm])
+
+
+def g7_multiscale(store):
+    for L in (2, 7, 10, 25, 26, 40):
+        torch.manual_seed(700 + L)
+        a = make_args(16, L)
+        m = ref.MultiScaleUserEncoder(16, 16, 64, 16, a)
+        xavier_(m)
+        pm = pad_mask(2, L, (0, L // 2))
+        module_case(store, f"G7_multiscale_L{L}", m, [torch.randn(2, L, 16) * pm, pm])
+
+
+def build_ref_model(U, I, d, L, dropout, seed):
+    a = make_args(d, L, dropout=dropout)
+    torch.manual_seed(seed)
+    with quiet():
+        se = ref_emb.SharedEmbeddingModule(U, I, {}, FEAT_TYPES, a, None)
+        m = ref.Hydra(U, I, {}, FEAT_TYPES, a, se)
+    for _, p in m.named_parameters():                                  # main.py:603-607
+        try:
+            torch.nn.init.xavier_normal_(p.data)
+        except Exception:
+            pass
+    for t in (se.pos_emb, se.item_emb, se.user_emb, se.action_emb):    # main.py:619-622
+        t.weight.data[0, :] = 0
+    return m, a
+
+
+def synth_batch(B, L, U, I, pads, seed, user_slot=True):
+    g = torch.Generator().manual_seed(seed)
+    seq = torch.randint(1, I + 1, (B, L), generator=g)
+    tok = torch.ones(B, L, dtype=torch.long)
+    ts = torch.cumsum(torch.randint(1, 100000, (B, L), generator=g), dim=1)
+    for b, p in enumerate(pads):
+        seq[b, :p] = 0
+        tok[b, :p] = 0
+        ts[b, :p] = 0
+        if user_slot and p < L:
+            seq[b, p] = int(torch.randint(1, U + 1, (1,), generator=g))
+            tok[b, p] = 2
+    # dt edge cases: a zero interval, a huge interval (bin clamp is never hit below e^511; keeps log large)
+    ts[0, -1] = ts[0, -2]
+    ts[-1, -1] = ts[-1, -2] + 10 ** 12
+    act = torch.randint(0, 6, (B, L), generator=g) * (seq != 0)
+    dwell = torch.randint(0, 7, (B, L), generator=g) * (seq != 0)
+    pos = torch.randint(1, I + 1, (B, L), generator=g) * (seq != 0)
+    neg = torch.randint(1, I + 1, (B, L), generator=g) * (seq != 0)
+    next_tok = torch.ones(B, L, dtype=torch.long) * (seq != 0)
+    return dict(seq=seq, tok=tok, ts=ts, act=act, dwell=dwell, pos=pos, neg=neg, next_tok=next_tok)
+
+
+def g8_log2feats(store, keys_out):
+    for d, L, B, U, I in ((16, 30, 4, 40, 200), (64, 20, 3, 30, 120)):
+        m, a = build_ref_model(U, I, d, L, 0.2, seed=800 + d)
+        m.eval()
+        bt = synth_batch(B, L, U, I, pads=(0, 3, L - 2, L - 1)[:B], seed=810 + d)
+        feat = [[] for _ in range(B)]
+        with torch.no_grad():
+            out = m.log2feats(bt["seq"], feat, bt["tok"], bt["ts"], bt["act"], bt["dwell"])
+            ue = m.get_user_embedding(bt["seq"], feat, bt["tok"], bt["ts"], bt["act"], bt["dwell"])
+        prefix = f"G8_log2feats_d{d}"
+        put_params(store, prefix, m)
+        put(store, prefix, out=out, user_emb=ue, U=U, I=I, d=d, L=L, **bt)
+        if d == 64:
+            keys_out.update({k: list(v.shape) for k, v in m.state_dict().items()})
+
+
+def g9_topk(store):
+    """Seeds are searched until every consecutive score gap inside the top-51 / top-11 exceeds 3e-4, i.e. more
+    than 100x the fp32 rounding noise of a 16-term dot product with |score| ~ 16: the ids are then unambiguous."""
+    B, I, d, L = 6, 3000, 16, 9
+    for seed in range(900, 5000):
+        torch.manual_seed(seed)
+        table = torch.randn(I + 1, d)
+        table[0] = 0
+        users = torch.randn(B, d)
+        pos = torch.randint(1, I + 1, (B, L))
+        hist = torch.randint(0, I + 1, (B, L))
+        full = users @ table.t()
+        # make sure some excluded ids would otherwise be in the top-50
+        top = full.topk(5, dim=1).indices
+        pos[:, 0] = top[:, 0]
+        hist[:, 0] = top[:, 2]
+        masked = full.clone()
+        for b in range(B):
+            masked[b, pos[b]] = float("-inf")
+            masked[b, hist[b]] = float("-inf")
+        gap50 = (-masked.topk(51, dim=1).values.diff(dim=1)).min()
+        gap10 = (-full.topk(11, dim=1).values.diff(dim=1)).min()
+        if gap50 > 3e-4 and gap10 > 3e-4:
+            break
+    else:
+        raise RuntimeError("no tie-free seed found")
+    miner = ref.HardNegativeMiner(None, table, top_k=50)
+    ids50 = miner.mine_hard_negatives_similarity(users, positive_items=pos, exclude_items=hist)
+    val10, ids10 = torch.topk(users @ table.t(), 10, dim=1)
+    put(store, "G9_topk", table=table, users=users, pos=pos, hist=hist, ids50=ids50, ids10=ids10, val10=val10,
+        min_gap50=gap50, min_gap10=gap10, seed=seed)
+
+
+def g10_train(store):
+    for name, (B, L, U, I) in {"small": (3, 12, 20, 400), "chunky": (8, 60, 30, 500)}.items():
+        d = 16
+        m, a = build_ref_model(U, I, d, L, 0.0, seed=1000 + B)
+        m.train()
+        bt = synth_batch(B, L, U, I, pads=(0, 2, L - 3, 5, 0, 0, 1, 7)[:B], seed=1010 + B)
+        feat = [[] for _ in range(B)]
+        torch.manual_seed(4242)
+        with quiet():
+            loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat,
+                     bt["ts"], bt["act"], bt["dwell"])
+        loss.backward()
+        prefix = f"G10_train_{name}"
+        put_params(store, prefix, m)
+        put(store, prefix, loss=loss, rng_seed=4242, U=U, I=I, d=d, L=L, **bt)
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.detach()
+            if k.endswith(("item_emb.weight", "user_emb.weight")):
+                rows = g.abs().sum(1).nonzero().flatten()
+                store[f"{prefix}/grad_rows/{k}"] = rows.numpy()
+                store[f"{prefix}/grad_vals/{k}"] = g[rows].numpy()
+                assert float(g[0].abs().sum()) == 0.0
+            else:
+                store[f"{prefix}/grad/{k}"] = g.numpy()
+
+
+def main():
+    groups = {"g1_pscan": g1_pscan, "g2_selective_scan": g2_selective_scan, "g3_rmsnorm": g3_rmsnorm,
+              "g4_mamba": g4_mamba, "g5_mhm": g5_mhm, "g6_blocks": g6_blocks, "g7_multiscale": g7_multiscale,
+              "g9_topk": g9_topk, "g10_train": g10_train}
+    for fname, fn in groups.items():
+        store = {}
+        fn(store)
+        np.savez_compressed(os.path.join(OUT, fname + ".npz"), **store)
+        print(fname, len(store), "arrays")
+    store, keys = {}, {}
+    g8_log2feats(store, keys)
+    np.savez_compressed(os.path.join(OUT, "g8_log2feats.npz"), **store)
+    with open(os.path.join(OUT, "state_dict_keys_d64_L20.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    print("g8_log2feats", len(store), "arrays;", len(keys), "state_dict keys")
+
+
+if __name__ == "__main__":
+    main()

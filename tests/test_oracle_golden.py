@@ -1,0 +1,160 @@
+"""Pin the CPU oracle against golden vectors produced by the reference's own code.
+
+Tolerances: the oracle runs the same fp32 math in a different association order
+(sequential recurrence vs Blelloch sweep), so values agree to a few fp32 ulps of the
+largest intermediate; 2e-5 relative / 2e-5 absolute is asserted.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import _golden as G
+from oracle import hydra_oracle as O
+
+RT, AT = 2e-5, 2e-5
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 10, 25, 64, 100, 101, 512])
+def test_pscan(L):
+    s, p = G.load("g1_pscan"), f"G1_pscan_L{L}"
+    A = G.t(s, p + "/A").requires_grad_()
+    X = G.t(s, p + "/X").requires_grad_()
+    H = O.pscan(A, X)
+    H.backward(G.t(s, p + "/G"))
+    G.assert_close(H, G.t(s, p + "/H"), RT, AT, "H")
+    G.assert_close(A.grad, G.t(s, p + "/dA"), 1e-4, 1e-4, "dA")
+    G.assert_close(X.grad, G.t(s, p + "/dX"), 1e-4, 1e-4, "dX")
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_selective_scan(case):
+    s, p = G.load("g2_selective_scan"), f"G2_sscan_{case}"
+    names = ["x", "delta", "A", "B", "C", "D"]
+    ins = [G.t(s, f"{p}/{n}").requires_grad_() for n in names]
+    y = O.selective_scan(*ins)
+    y.backward(G.t(s, p + "/G"))
+    G.assert_close(y, G.t(s, p + "/y"), RT, AT, "y")
+    for n, v in zip(names, ins):
+        G.assert_close(v.grad, G.t(s, f"{p}/d{n}"), 1e-4, 1e-4, "d" + n)
+
+
+def test_rmsnorm():
+    s, p = G.load("g3_rmsnorm"), "G3_rmsnorm"
+    m = O.RMSNorm(16)
+    m.scale.data = G.t(s, p + "/scale")
+    x = G.t(s, p + "/x").requires_grad_()
+    y = m(x)
+    y.backward(G.t(s, p + "/G"))
+    G.assert_close(y, G.t(s, p + "/y"), RT, AT)
+    G.assert_close(x.grad, G.t(s, p + "/dx"), 1e-4, 1e-4)
+    G.assert_close(m.scale.grad, G.t(s, p + "/dscale"), 1e-4, 1e-4)
+
+
+def _run_module_case(store, prefix, module, n_in, grad_inputs=(0,)):
+    module.load_state_dict(G.params(store, prefix), strict=True)
+    module.eval()
+    ins = []
+    for i in range(n_in):
+        v = G.t(store, f"{prefix}/in{i}")
+        ins.append(v.requires_grad_() if i in grad_inputs else v)
+    y = module(*ins)
+    y.backward(G.t(store, prefix + "/G"))
+    G.assert_close(y, G.t(store, prefix + "/y"), RT, AT, prefix + " y")
+    for i in grad_inputs:
+        G.assert_close(ins[i].grad, G.t(store, f"{prefix}/din{i}"), 2e-4, 2e-4, f"{prefix} din{i}")
+    gold = G.grads(store, prefix)
+    got = {k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+    assert set(gold) == set(got), (set(gold) ^ set(got))
+    for k in gold:
+        G.assert_close(got[k], gold[k], 3e-4, 3e-4, f"{prefix} grad {k}")
+
+
+@pytest.mark.parametrize("hd", [8, 32])
+def test_mamba_block(hd):
+    _run_module_case(G.load("g4_mamba"), f"G4_mamba_hd{hd}", O.MambaBlock(hd, 16, 4 * hd, 16), 1)
+
+
+def test_multi_head_mamba():
+    m = O.MultiHeadMamba(16, 16, 64, 16, O.make_args(16, 12))
+    _run_module_case(G.load("g5_mhm"), "G5_mhm", m, 3, grad_inputs=(0, 1))
+
+
+@pytest.mark.parametrize("name,cls", [("first", O.HydraBlockFirst), ("regular", O.HydraBlock)])
+def test_hydra_blocks(name, cls):
+    _run_module_case(G.load("g6_blocks"), f"G6_block_{name}", cls(16, 16, 64, 16, O.make_args(16, 14)), 2)
+
+
+@pytest.mark.parametrize("L", [2, 7, 10, 25, 26, 40])
+def test_multiscale(L):
+    m = O.MultiScaleUserEncoder(16, 16, 64, 16, O.make_args(16, L))
+    _run_module_case(G.load("g7_multiscale"), f"G7_multiscale_L{L}", m, 2)
+
+
+def _model_from(store, prefix, dropout=0.2):
+    U, I, d, L = (int(store[f"{prefix}/{k}"]) for k in "UIdL")
+    args = O.make_args(d, L, dropout=dropout)
+    m = O.Hydra(U, I, {}, O.IDS_ONLY_FEAT_TYPES, args, O.SharedEmbeddingModule(U, I, {}, O.IDS_ONLY_FEAT_TYPES, args))
+    m.load_state_dict(G.params(store, prefix), strict=True)
+    return m
+
+
+@pytest.mark.parametrize("d", [16, 64])
+def test_log2feats(d):
+    s, p = G.load("g8_log2feats"), f"G8_log2feats_d{d}"
+    m = _model_from(s, p).eval()
+    b = {k: G.t(s, f"{p}/{k}") for k in ("seq", "tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    with torch.no_grad():
+        out = m.log2feats(b["seq"], feat, b["tok"], b["ts"], b["act"], b["dwell"])
+        ue = m.get_user_embedding(b["seq"], feat, b["tok"], b["ts"], b["act"], b["dwell"])
+    G.assert_close(out, G.t(s, p + "/out"), 5e-5, 5e-5, "log2feats")
+    G.assert_close(ue, G.t(s, p + "/user_emb"), 5e-5, 5e-5, "user_emb")
+    assert torch.all(out[b["seq"] == 0] == 0)          # padded positions are exactly zero
+
+
+def test_state_dict_keys_match_reference():
+    with open(os.path.join(G.GOLDEN_DIR, "state_dict_keys_d64_L20.json")) as f:
+        gold = json.load(f)
+    m = O.build_model(30, 120, d=64, L=20)
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert got == gold
+    assert len(got) == 190
+
+
+def test_topk_and_miner():
+    s, p = G.load("g9_topk"), "G9_topk"
+    table, users = G.t(s, p + "/table"), G.t(s, p + "/users")
+    assert float(s[p + "/min_gap50"]) > 3e-4 and float(s[p + "/min_gap10"]) > 3e-4   # goldens are tie-free
+    ids50, _ = O.mine_hard_negatives_similarity(users, table, 50, G.t(s, p + "/pos"), G.t(s, p + "/hist"))
+    assert torch.equal(ids50, G.t(s, p + "/ids50"))
+    ids10, val10 = O.mine_hard_negatives_similarity(users, table, 10)
+    assert torch.equal(ids10, G.t(s, p + "/ids10"))
+    G.assert_close(val10, G.t(s, p + "/val10"), 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["small", "chunky"])
+def test_train_step_loss_and_grads(name):
+    s, p = G.load("g10_train"), f"G10_train_{name}"
+    m = _model_from(s, p, dropout=0.0).train()
+    b = {k: G.t(s, f"{p}/{k}") for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    torch.manual_seed(int(s[p + "/rng_seed"]))
+    loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, feat, feat, feat,
+             b["ts"], b["act"], b["dwell"])
+    loss.backward()
+    G.assert_close(loss, G.t(s, p + "/loss"), 2e-5, 2e-5, "loss")
+    gold = G.grads(s, p)
+    got = {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
+    tables = {k for k in got if k.endswith(("item_emb.weight", "user_emb.weight"))}
+    assert set(gold) == set(got) - tables
+    for k in gold:
+        G.assert_close(got[k], gold[k], 1e-3, 2e-5, "grad " + k)
+    for k in tables:
+        rows = G.t(s, f"{p}/grad_rows/{k}")
+        vals = G.t(s, f"{p}/grad_vals/{k}")
+        g = got[k]
+        assert torch.equal(g.abs().sum(1).nonzero().flatten(), rows), k
+        G.assert_close(g[rows], vals, 1e-3, 2e-5, "table grad " + k)
+        assert float(g[0].abs().sum()) == 0.0
