@@ -1,0 +1,39 @@
+// Shared helpers for the libhmx.so kernels (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hmx.h"
+
+#define HMX_WAVE 64
+
+#define HMX_CHECK_LAUNCH()                            \
+    do {                                              \
+        hipError_t e_ = hipGetLastError();            \
+        if (e_ != hipSuccess) return HMX_ELAUNCH;     \
+    } while (0)
+
+static inline int64_t hmx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t hmx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Carves consecutive 256-byte aligned regions out of a caller-provided workspace.
+struct HmxCarver {
+    char* base;
+    size_t off;
+    explicit HmxCarver(void* p) : base(static_cast<char*>(p)), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* r = reinterpret_cast<T*>(base + off);
+        off += hmx_align_up(count * sizeof(T), 256);
+        return r;
+    }
+};
+
+// round-to-nearest-even fp32 -> bf16 bits (finite inputs; NaN stays NaN via the quiet bit)
+__device__ __forceinline__ uint16_t hmx_f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float hmx_bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

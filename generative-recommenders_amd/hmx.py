@@ -1,0 +1,66 @@
+"""ctypes binding of libhmx.so (C ABI declared in include/hmx.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmx.so")
+
+P = c_void_p
+I64 = c_int64
+
+# name -> (restype, argtypes); must list every symbol declared in include/hmx.h
+PROTOTYPES = {
+    "hmx_abi_version": (c_int, []),
+    "hmx_error_string": (c_char_p, [c_int]),
+    "hmx_gather_rows_f32": (c_int, [P, I64, I64, P, I64, P, P]),
+    "hmx_gather_routed_f32": (c_int, [P, I64, P, I64, I64, P, P, I64, P, P]),
+    "hmx_scatter_add_rows_workspace_bytes": (c_size_t, [I64, I64]),
+    "hmx_scatter_add_rows_f32": (c_int, [P, P, P, I64, I64, I64, P, I64, I64, P, c_size_t, P]),
+    "hmx_table_prepare_bf16": (c_int, [P, I64, I64, P, P, P]),
+    "hmx_score_topk_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
+    "hmx_score_topk_f32": (c_int, [P, I64, P, I64, I64, I64, P, I64, I64, P, P, P, c_size_t, P]),
+    "hmx_score_topk_bf16": (c_int, [P, I64, P, P, P, I64, I64, I64, P, I64, I64, P, P, P, P, c_size_t, P]),
+    "hmx_topk_merge": (c_int, [P, P, I64, I64, I64, P, P, P]),
+}
+
+_lib = None
+
+
+class HmxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libhmx.so once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HmxError(f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                continue                      # reported by check_exports(); calling it raises AttributeError
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise HmxError(f"{what} failed: {lib().hmx_error_string(code).decode()} ({code})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,115 @@
+"""torch.autograd wrappers around the libhmx.so C ABI.
+
+Every function here requires CUDA (ROCm) fp32 tensors and calls the HIP kernels; there is
+no eager/CPU fallback -- a missing library or a wrong device raises.
+"""
+import os
+
+import torch
+
+from . import hmx
+
+CHECK_IDS = os.environ.get("HMX_CHECK_IDS", "0") == "1"
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise hmx.HmxError("hmx ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise hmx.HmxError(f"expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _i64c(t):
+    if t.dtype != torch.int64:
+        t = t.long()
+    return t.contiguous()
+
+
+def _validate_ids(ids, n_rows, what):
+    """Opt-in host check reproducing nn.Embedding's IndexError (costs a device sync)."""
+    if CHECK_IDS and ids.numel():
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo < 0 or hi >= n_rows:
+            raise IndexError(f"{what}: index out of range in self (min {lo}, max {hi}, rows {n_rows})")
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def scatter_add_rows(grad_rows, ids, n_rows, padding_idx=-1, token_type=None, want_type=0, out=None):
+    """Dense (n_rows, d) gradient: out[ids[i]] += grad_rows[i] (deterministic)."""
+    _need_cuda(grad_rows, ids, token_type)
+    d = grad_rows.shape[-1]
+    g = _f32c(grad_rows).view(-1, d)
+    ids = _i64c(ids).view(-1)
+    tt = _i64c(token_type).view(-1) if token_type is not None else None
+    n = ids.numel()
+    assert g.shape[0] == n
+    if out is None:
+        out = torch.zeros(n_rows, d, dtype=torch.float32, device=g.device)
+    L = hmx.lib()
+    ws = workspace(L.hmx_scatter_add_rows_workspace_bytes(n, n_rows), g.device)
+    hmx.check(L.hmx_scatter_add_rows_f32(hmx.ptr(g), hmx.ptr(ids), hmx.ptr(tt), want_type, n, d, hmx.ptr(out), n_rows,
+                                         padding_idx, hmx.ptr(ws), ws.numel(), hmx.current_stream()),
+              "hmx_scatter_add_rows_f32")
+    return out
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, ids, padding_idx):
+        _need_cuda(weight, ids)
+        w = _f32c(weight)
+        idc = _i64c(ids)
+        _validate_ids(idc, w.shape[0], "gather_rows")
+        out = torch.empty(*idc.shape, w.shape[1], dtype=torch.float32, device=w.device)
+        hmx.check(hmx.lib().hmx_gather_rows_f32(hmx.ptr(w), w.shape[0], w.shape[1], hmx.ptr(idc), idc.numel(),
+                                                hmx.ptr(out), hmx.current_stream()), "hmx_gather_rows_f32")
+        ctx.save_for_backward(idc)
+        ctx.n_rows, ctx.padding_idx = w.shape[0], -1 if padding_idx is None else padding_idx
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idc,) = ctx.saved_tensors
+        gw = scatter_add_rows(grad_out, idc, ctx.n_rows, ctx.padding_idx) if ctx.needs_input_grad[0] else None
+        return gw, None, None
+
+
+def gather_rows(weight, ids, padding_idx=None):
+    """out[..., :] = weight[ids[...], :]  (nn.Embedding forward; dense deterministic backward)."""
+    return _GatherRows.apply(weight, ids, padding_idx)
+
+
+class _GatherRouted(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, item_w, user_w, ids, token_type):
+        _need_cuda(item_w, user_w, ids, token_type)
+        iw, uw = _f32c(item_w), _f32c(user_w)
+        idc, tt = _i64c(ids), _i64c(token_type)
+        assert idc.shape == tt.shape and iw.shape[1] == uw.shape[1]
+        out = torch.empty(*idc.shape, iw.shape[1], dtype=torch.float32, device=iw.device)
+        hmx.check(hmx.lib().hmx_gather_routed_f32(hmx.ptr(iw), iw.shape[0], hmx.ptr(uw), uw.shape[0], iw.shape[1],
+                                                  hmx.ptr(idc), hmx.ptr(tt), idc.numel(), hmx.ptr(out),
+                                                  hmx.current_stream()), "hmx_gather_routed_f32")
+        ctx.save_for_backward(idc, tt)
+        ctx.rows = (iw.shape[0], uw.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idc, tt = ctx.saved_tensors
+        gi = scatter_add_rows(grad_out, idc, ctx.rows[0], 0, tt, 1) if ctx.needs_input_grad[0] else None
+        gu = scatter_add_rows(grad_out, idc, ctx.rows[1], 0, tt, 2) if ctx.needs_input_grad[1] else None
+        return gi, gu, None, None
+
+
+def gather_routed(item_weight, user_weight, ids, token_type):
+    """embedding.py:436-450: item rows where token_type==1, user rows where ==2, zeros elsewhere."""
+    return _GatherRouted.apply(item_weight, user_weight, ids, token_type)
