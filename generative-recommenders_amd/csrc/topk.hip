@@ -1,0 +1,684 @@
+// Full-table inner-product scoring fused with a per-lane partial top-K (no score matrix in HBM).
+//
+// Geometry.  One 64-lane wave = one workgroup = (a tile of 32*NB queries) x (one item range).
+// Scores are produced by 32x32 MFMA tiles with ITEMS on the rows (A operand) and QUERIES on
+// the columns (B operand), so in the accumulator layout
+//     col = lane & 31,  row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+// every lane owns ONE query and sixteen of the tile's items: the top-K filter needs no
+// cross-lane traffic.  Each lane keeps, for its (query, item subset), a private candidate
+// list in a workspace buffer: a score enters when it beats the lane's threshold; when the
+// list is nearly full the wave sorts it cooperatively (all-pairs rank through v_readlane),
+// keeps the best KP and raises the threshold to the KP-th best.  A second kernel re-scores
+// every surviving candidate exactly (fp32 fma chain in k order over the fp32 table), extracts
+// the K best with the (score desc, id asc) order and -- for the bf16 coarse pass -- proves
+// per query that nothing dropped could have ranked: K-th exact score > largest threshold +
+// error bound of the coarse score.  Queries failing the proof are flagged, not guessed.
+//
+// Coarse pass, bf16:  v_mfma_f32_32x32x16_bf16, item rows read straight from L2/HBM as
+//   16-byte fragments (each A fragment feeds NB MFMAs), query fragments resident in VGPRs.
+// Coarse pass, fp32:  v_mfma_f32_32x32x2_f32, bit-identical to the fma chain, so its
+//   thresholds are exact and every query is certain.
+#include <algorithm>
+#include <cmath>
+
+#include "hmx_common.h"
+
+namespace {
+
+using short8 = __attribute__((ext_vector_type(8))) short;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float kNegInf = -INFINITY;
+constexpr int kRoom = 16;  // free slots guaranteed before a tile's epilogue (one lane sees 16 scores per tile)
+
+struct CoarseParams {
+    const uint16_t* q_bf16;   // (n_q_pad, dpad) bf16   [bf16 pass]
+    const uint16_t* t_bf16;   // (n_rows, dpad) bf16    [bf16 pass]
+    const float* q_f32;       // (n_q, d)               [fp32 pass]
+    const float* t_f32;       // (n_rows, d)            [fp32 pass]
+    int64_t n_q;              // queries in this chunk
+    int64_t n_rows;
+    int d, dpad;
+    int n_qtiles, n_splits;
+    int64_t rows_per_split;
+    const int64_t* exclude;   // (n_q, n_excl) global ids or null
+    int n_excl;
+    int64_t id_offset;
+    uint2* cand;              // [wave][g][lane][CAP] (score bits, local row)
+    int* meta_cnt;            // [wave][g][lane]
+    float* meta_thr;          // [wave][g][lane]
+};
+
+__device__ __forceinline__ void decode_wave(const CoarseParams& p, int& qtile, int& split) {
+    const int b = blockIdx.x;
+    if (p.n_splits % 8 == 0) {
+        // blocks b and b+8 share an XCD (round-robin dispatch): keep a split's item range on one L2
+        const int x = b & 7, r = b >> 3;
+        qtile = r % p.n_qtiles;
+        split = x + 8 * (r / p.n_qtiles);
+    } else {
+        qtile = b % p.n_qtiles;
+        split = b / p.n_qtiles;
+    }
+}
+
+// Cooperative compaction of one lane's candidate list (wave-uniform call).
+// buf: that lane's CAP slots; n: its entry count.  Leaves min(n, KP) entries sorted by
+// (score desc, arrival asc == row asc) and returns the new threshold.
+template <int KP>
+__device__ __forceinline__ void compact_list(uint2* buf, int n, int& new_cnt, float& new_thr, float old_thr) {
+    constexpr int CAP = 2 * KP, EPL = CAP / 64;
+    const int lane = threadIdx.x;
+    float s[EPL];
+    unsigned id[EPL];
+    int rank[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int e = lane + 64 * t;
+        uint2 v = (e < n) ? buf[e] : make_uint2(__float_as_uint(kNegInf), 0xffffffffu);
+        s[t] = __uint_as_float(v.x);
+        id[t] = v.y;
+        rank[t] = 0;
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < EPL; ++t2) {
+        const int lim = min(64, n - 64 * t2);
+        for (int f = 0; f < lim; ++f) {
+            const float sf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s[t2]), f));
+            const int ef = f + 64 * t2;
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) {
+                const int e = lane + 64 * t;
+                rank[t] += (sf > s[t] || (sf == s[t] && ef < e)) ? 1 : 0;
+            }
+        }
+    }
+    new_thr = old_thr;
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) {
+        const int e = lane + 64 * t;
+        const bool valid = e < n;
+        if (valid && rank[t] < KP) buf[rank[t]] = make_uint2(__float_as_uint(s[t]), id[t]);
+        const unsigned long long m = __ballot(valid && rank[t] == KP - 1);
+        if (m) {
+            const int src = __ffsll((long long)m) - 1;
+            new_thr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s[t]), src));
+        }
+    }
+    new_cnt = n < KP ? n : KP;
+}
+
+// Per-tile filter for one group of 32 queries.  acc: the 32x32 score tile; row0: local table
+// row of accumulator register 0 for this lane (tile base + 4 * (lane >> 5)).
+template <int KP, bool EXCL>
+__device__ __forceinline__ void tile_filter(const f32x16& acc, float& thr, int& cnt, uint2* group_buf, int64_t row0,
+                                            int64_t row_end, const CoarseParams& p, int64_t q_global) {
+    constexpr int CAP = 2 * KP;
+    float m = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+    if (__ballot(m > thr) == 0ull) return;  // wave-uniform fast path
+    uint2* mine = group_buf + (int64_t)threadIdx.x * CAP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+        bool pass = acc[r] > thr && row < row_end;
+        if (EXCL) {
+            if (pass && q_global < p.n_q) {
+                const int64_t gid = row + p.id_offset;
+                const int64_t* ex = p.exclude + q_global * p.n_excl;
+                for (int e = 0; e < p.n_excl; ++e) pass = pass && (ex[e] != gid);
+            }
+        }
+        if (pass) {
+            mine[cnt] = make_uint2(__float_as_uint(acc[r]), (unsigned)row);
+            ++cnt;
+        }
+    }
+    unsigned long long need = __ballot(cnt > CAP - kRoom);
+    while (need) {
+        const int o = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int n = __builtin_amdgcn_readlane(cnt, o);
+        const float t_old = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr), o));
+        int nc;
+        float nt;
+        compact_list<KP>(group_buf + (int64_t)o * CAP, n, nc, nt, t_old);
+        if ((int)threadIdx.x == o) {
+            cnt = nc;
+            thr = nt;
+        }
+    }
+}
+
+template <int KP>
+__device__ __forceinline__ void finish_group(float& thr, int& cnt, uint2* group_buf, int* meta_cnt, float* meta_thr) {
+    constexpr int CAP = 2 * KP;
+    unsigned long long need = __ballot(cnt > KP);
+    while (need) {
+        const int o = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int n = __builtin_amdgcn_readlane(cnt, o);
+        const float t_old = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr), o));
+        int nc;
+        float nt;
+        compact_list<KP>(group_buf + (int64_t)o * CAP, n, nc, nt, t_old);
+        if ((int)threadIdx.x == o) {
+            cnt = nc;
+            thr = nt;
+        }
+    }
+    meta_cnt[threadIdx.x] = cnt;
+    meta_thr[threadIdx.x] = thr;
+}
+
+template <int NB, int KS, int KP, bool EXCL>
+__global__ __launch_bounds__(64) void coarse_bf16_kernel(CoarseParams p) {
+    constexpr int CAP = 2 * KP;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    int qtile, split;
+    decode_wave(p, qtile, split);
+    const int64_t wave = (int64_t)qtile * p.n_splits + split;
+    const int64_t row_begin = (int64_t)split * p.rows_per_split;
+    const int64_t row_end = min(row_begin + p.rows_per_split, p.n_rows);
+    uint2* wave_buf = p.cand + wave * NB * 64 * CAP;
+
+    short8 bq[NB][KS];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const int64_t qrow = (int64_t)qtile * 32 * NB + 32 * g + j;  // q_bf16 is padded to a multiple of 32*NB rows
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            bq[g][ks] = *reinterpret_cast<const short8*>(p.q_bf16 + qrow * p.dpad + 16 * ks + 8 * h);
+    }
+    float thr[NB];
+    int cnt[NB];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        thr[g] = kNegInf;
+        cnt[g] = 0;
+    }
+
+    short8 a_cur[KS], a_nxt[KS];
+    {
+        const int64_t r = min(row_begin + j, p.n_rows - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            a_cur[ks] = *reinterpret_cast<const short8*>(p.t_bf16 + r * p.dpad + 16 * ks + 8 * h);
+    }
+    for (int64_t i0 = row_begin; i0 < row_end; i0 += 32) {
+        {
+            const int64_t r = min(i0 + 32 + j, p.n_rows - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                a_nxt[ks] = *reinterpret_cast<const short8*>(p.t_bf16 + r * p.dpad + 16 * ks + 8 * h);
+        }
+        f32x16 acc[NB];
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[ks], bq[g][ks], acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+            tile_filter<KP, EXCL>(acc[g], thr[g], cnt[g], wave_buf + (int64_t)g * 64 * CAP, i0 + 4 * h, row_end, p,
+                                  (int64_t)qtile * 32 * NB + 32 * g + j);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+    }
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+        finish_group<KP>(thr[g], cnt[g], wave_buf + (int64_t)g * 64 * CAP, p.meta_cnt + (wave * NB + g) * 64,
+                         p.meta_thr + (wave * NB + g) * 64);
+}
+
+// fp32 MFMA: D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) per instruction, k0 on lanes 0-31, k1 on 32-63,
+// so stepping k by 2 reproduces the k-ordered fma chain bit for bit.
+template <int KP, bool EXCL>
+__global__ __launch_bounds__(64) void coarse_f32_kernel(CoarseParams p) {
+    constexpr int CAP = 2 * KP;
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    int qtile, split;
+    decode_wave(p, qtile, split);
+    const int64_t wave = (int64_t)qtile * p.n_splits + split;
+    const int64_t row_begin = (int64_t)split * p.rows_per_split;
+    const int64_t row_end = min(row_begin + p.rows_per_split, p.n_rows);
+    uint2* wave_buf = p.cand + wave * 64 * CAP;
+    const int64_t q_global = (int64_t)qtile * 32 + j;
+    const float* qrow = p.q_f32 + min(q_global, p.n_q - 1) * p.d;
+    float thr = kNegInf;
+    int cnt = 0;
+    const int steps = (p.d + 1) / 2;
+    for (int64_t i0 = row_begin; i0 < row_end; i0 += 32) {
+        const float* trow = p.t_f32 + min(i0 + j, p.n_rows - 1) * p.d;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        for (int s = 0; s < steps; ++s) {
+            const int k = 2 * s + h;
+            const bool in = k < p.d;
+            const float a = in ? trow[k] : 0.f;
+            const float b = in ? qrow[k] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        tile_filter<KP, EXCL>(acc, thr, cnt, wave_buf, i0 + 4 * h, row_end, p, q_global);
+    }
+    finish_group<KP>(thr, cnt, wave_buf, p.meta_cnt + wave * 64, p.meta_thr + wave * 64);
+}
+
+// ------------------------------------------------------------------ exact re-score + select
+struct RescoreParams {
+    const float* q_f32;   // (n_q, d) this chunk
+    const float* t_f32;   // (n_rows, d)
+    int64_t n_q, n_rows;
+    int d;
+    int NB, KP, n_splits;
+    const uint2* cand;
+    const int* meta_cnt;
+    const float* meta_thr;
+    int k;
+    int64_t id_offset;
+    const float* max_row_norm;  // null => exact coarse pass (no proof needed)
+    int64_t* out_ids;           // (n_q, k)
+    float* out_scores;
+    int32_t* uncertain;         // (n_q) or null
+};
+
+__device__ __forceinline__ bool ranks_before(float sa, int64_t ia, float sb, int64_t ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+template <int TPQ, int CPT>
+__global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
+    constexpr int QPB = 256 / TPQ;
+    constexpr int64_t kNoId = 0x7fffffffffffffffll;
+    __shared__ float sh_s[4];
+    __shared__ int64_t sh_i[4];
+    const int t = threadIdx.x % TPQ;
+    const int64_t q = (int64_t)blockIdx.x * QPB + threadIdx.x / TPQ;
+    const bool q_ok = q < p.n_q;
+    const int CAP = 2 * p.KP;
+    const int n_cand = p.n_splits * 2 * p.KP;
+    const int qtile = (int)(q / (32 * p.NB)), g = (int)((q / 32) % p.NB), jq = (int)(q % 32);
+    const float* qv = p.q_f32 + (q_ok ? q : 0) * p.d;
+
+    float sc[CPT];
+    int64_t id[CPT];
+    float tmax = kNegInf;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = t + TPQ * i;
+        sc[i] = kNegInf;
+        id[i] = kNoId;
+        if (q_ok && c < n_cand) {
+            const int split = c / (2 * p.KP), hh = (c / p.KP) & 1, e = c % p.KP;
+            const int64_t wave = (int64_t)qtile * p.n_splits + split;
+            const int64_t lane_slot = (wave * p.NB + g) * 64 + jq + 32 * hh;
+            if (e == 0) tmax = fmaxf(tmax, p.meta_thr[lane_slot]);
+            if (e < p.meta_cnt[lane_slot]) {
+                const int64_t row = p.cand[lane_slot * CAP + e].y;
+                const float* tv = p.t_f32 + row * p.d;
+                float a = 0.f;
+                for (int k = 0; k < p.d; ++k) a = __builtin_fmaf(qv[k], tv[k], a);
+                sc[i] = a;
+                id[i] = row + p.id_offset;
+            }
+        }
+    }
+    // largest coarse threshold of any lane that served this query
+    for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+    if (TPQ == 256) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh_s[threadIdx.x >> 6] = tmax;
+        __syncthreads();
+        tmax = fmaxf(fmaxf(sh_s[0], sh_s[1]), fmaxf(sh_s[2], sh_s[3]));
+        __syncthreads();
+    }
+    float kth = kNegInf;
+    for (int r = 0; r < p.k; ++r) {
+        float bs = sc[0];
+        int64_t bi = id[0];
+#pragma unroll
+        for (int i = 1; i < CPT; ++i)
+            if (ranks_before(sc[i], id[i], bs, bi)) {
+                bs = sc[i];
+                bi = id[i];
+            }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off);
+            const int64_t oi = __shfl_xor(bi, off);
+            if (ranks_before(os, oi, bs, bi)) {
+                bs = os;
+                bi = oi;
+            }
+        }
+        if (TPQ == 256) {
+            if ((threadIdx.x & 63) == 0) {
+                sh_s[threadIdx.x >> 6] = bs;
+                sh_i[threadIdx.x >> 6] = bi;
+            }
+            __syncthreads();
+            bs = sh_s[0];
+            bi = sh_i[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (ranks_before(sh_s[w], sh_i[w], bs, bi)) {
+                    bs = sh_s[w];
+                    bi = sh_i[w];
+                }
+            __syncthreads();
+        }
+        const bool found = bi != kNoId;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            if (found && id[i] == bi) {
+                sc[i] = kNegInf;
+                id[i] = kNoId;
+            }
+        if (q_ok && t == 0) {
+            p.out_ids[q * p.k + r] = found ? bi : -1;
+            p.out_scores[q * p.k + r] = found ? bs : kNegInf;
+        }
+        kth = found ? bs : kNegInf;
+    }
+    if (p.uncertain != nullptr && q_ok && t == 0) {
+        int flag = 0;
+        if (p.max_row_norm != nullptr && tmax > kNegInf) {
+            float n2 = 0.f;
+            for (int k = 0; k < p.d; ++k) n2 = __builtin_fmaf(qv[k], qv[k], n2);
+            // |bf16 coarse score - exact score| <= (2^-8 + small) * |q| * max|t|   (two bf16 roundings per product)
+            const float eps = 0.00398f * sqrtf(n2) * p.max_row_norm[0];
+            flag = !(kth > tmax + eps);
+        }
+        p.uncertain[q] = flag;
+    }
+}
+
+// ------------------------------------------------------------------ conversions / merge
+__global__ __launch_bounds__(256) void to_bf16_padded_kernel(const float* __restrict__ src, int64_t rows, int d,
+                                                             int64_t rows_pad, int dpad, uint16_t* __restrict__ dst,
+                                                             unsigned* __restrict__ max_norm_bits) {
+    // one 16-lane group per output row chunk; row norm reduced inside the group
+    const int lpr = 16;
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const int c = threadIdx.x % lpr;
+    float n2 = 0.f;
+    if (row < rows_pad) {
+        for (int k = c; k < dpad; k += lpr) {
+            const float v = (row < rows && k < d) ? src[row * d + k] : 0.f;
+            n2 += v * v;
+            dst[row * dpad + k] = hmx_f32_to_bf16(v);
+        }
+    }
+    if (max_norm_bits != nullptr) {
+        for (int off = 8; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
+        for (int off = 32; off >= 16; off >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, off));
+        // slightly inflated so that the rounding of this reduction can never under-state a norm
+        if ((threadIdx.x & 63) == 0) atomicMax(max_norm_bits, __float_as_uint(sqrtf(n2) * 1.0001f));
+    }
+}
+
+__global__ __launch_bounds__(64) void topk_merge_kernel(const int64_t* __restrict__ cand_ids,
+                                                        const float* __restrict__ cand_scores, int n_shards,
+                                                        int64_t n_q, int k, int64_t* __restrict__ out_ids,
+                                                        float* __restrict__ out_scores) {
+    constexpr int64_t kNoId = 0x7fffffffffffffffll;
+    constexpr int CPT = 16;  // up to 1024 candidates (n_shards * k)
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n_cand = n_shards * k;
+    float sc[CPT];
+    int64_t id[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = lane + 64 * i;
+        sc[i] = kNegInf;
+        id[i] = kNoId;
+        if (c < n_cand) {
+            const int s = c / k, e = c % k;
+            const int64_t ci = cand_ids[((int64_t)s * n_q + q) * k + e];
+            if (ci >= 0) {
+                id[i] = ci;
+                sc[i] = cand_scores[((int64_t)s * n_q + q) * k + e];
+            }
+        }
+    }
+    for (int r = 0; r < k; ++r) {
+        float bs = sc[0];
+        int64_t bi = id[0];
+#pragma unroll
+        for (int i = 1; i < CPT; ++i)
+            if (ranks_before(sc[i], id[i], bs, bi)) {
+                bs = sc[i];
+                bi = id[i];
+            }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off);
+            const int64_t oi = __shfl_xor(bi, off);
+            if (ranks_before(os, oi, bs, bi)) {
+                bs = os;
+                bi = oi;
+            }
+        }
+        const bool found = bi != kNoId;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            if (found && id[i] == bi) {
+                sc[i] = kNegInf;
+                id[i] = kNoId;
+            }
+        if (lane == 0) {
+            out_ids[q * k + r] = found ? bi : -1;
+            out_scores[q * k + r] = found ? bs : kNegInf;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host-side planning
+struct Plan {
+    int NB, KP, KS, dpad;
+    int64_t chunk;       // queries per launch
+    int n_qtiles;        // per full chunk
+    int n_splits;
+    int64_t rows_per_split;
+    size_t q_bf16_bytes, cand_bytes, meta_bytes;
+    size_t total() const { return q_bf16_bytes + cand_bytes + 2 * meta_bytes + 1024; }
+};
+
+int dpad_for(int64_t d) {
+    int p = 16;
+    while (p < d) p *= 2;
+    return p;
+}
+
+bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Plan& pl) {
+    if (n_q <= 0 || n_rows <= 0 || d <= 0 || k <= 0 || k > 64 || n_rows >= ((int64_t)1 << 31)) return false;
+    if (bf16 && d > 128) return false;
+    pl.KP = (k <= 16) ? 32 : 64;
+    pl.dpad = dpad_for(d);
+    pl.KS = pl.dpad / 16;
+    pl.NB = 1;
+    if (bf16) pl.NB = n_q >= 16384 ? 4 : (n_q >= 4096 ? 2 : 1);
+    const int64_t qpw = 32 * pl.NB;
+    pl.chunk = std::min<int64_t>(hmx_ceil_div(n_q, qpw) * qpw, 2048 * qpw);
+    pl.n_qtiles = (int)(pl.chunk / qpw);
+    int64_t s = hmx_ceil_div(2048, pl.n_qtiles);
+    s = std::min<int64_t>(s, 4096 / (2 * pl.KP));              // candidates per query <= 4096
+    s = std::min<int64_t>(s, std::max<int64_t>(1, n_rows / 2048));
+    if (s >= 8) s = s / 8 * 8;                                  // XCD-aware block mapping wants a multiple of 8
+    pl.n_splits = (int)std::max<int64_t>(1, s);
+    pl.rows_per_split = hmx_ceil_div(hmx_ceil_div(n_rows, pl.n_splits), 32) * 32;
+    const int64_t waves = (int64_t)pl.n_qtiles * pl.n_splits;
+    pl.q_bf16_bytes = bf16 ? hmx_align_up((size_t)pl.chunk * pl.dpad * 2, 256) : 0;
+    pl.cand_bytes = hmx_align_up((size_t)waves * pl.NB * 64 * (2 * pl.KP) * sizeof(uint2), 256);
+    pl.meta_bytes = hmx_align_up((size_t)waves * pl.NB * 64 * 4, 256);
+    return true;
+}
+
+template <int NB, int KS, int KP>
+void launch_bf16(const CoarseParams& p, int waves, bool excl, hipStream_t s) {
+    if (excl) hipLaunchKernelGGL((coarse_bf16_kernel<NB, KS, KP, true>), dim3(waves), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((coarse_bf16_kernel<NB, KS, KP, false>), dim3(waves), dim3(64), 0, s, p);
+}
+template <int NB, int KS>
+void launch_bf16_kp(const CoarseParams& p, int waves, int KP, bool excl, hipStream_t s) {
+    if (KP == 32) launch_bf16<NB, KS, 32>(p, waves, excl, s);
+    else launch_bf16<NB, KS, 64>(p, waves, excl, s);
+}
+template <int NB>
+void launch_bf16_ks(const CoarseParams& p, int waves, int KS, int KP, bool excl, hipStream_t s) {
+    switch (KS) {
+        case 1: launch_bf16_kp<NB, 1>(p, waves, KP, excl, s); break;
+        case 2: launch_bf16_kp<NB, 2>(p, waves, KP, excl, s); break;
+        case 4: launch_bf16_kp<NB, 4>(p, waves, KP, excl, s); break;
+        default: launch_bf16_kp<NB, 8>(p, waves, KP, excl, s); break;
+    }
+}
+
+void launch_rescore(const RescoreParams& r, hipStream_t s) {
+    const int n_cand = r.n_splits * 2 * r.KP;
+#define HMX_RS(TPQ, CPT)                                                                                          \
+    hipLaunchKernelGGL((rescore_select_kernel<TPQ, CPT>), dim3((unsigned)hmx_ceil_div(r.n_q, 256 / TPQ)), dim3(256), 0, \
+                       s, r)
+    if (n_cand <= 64) HMX_RS(64, 1);
+    else if (n_cand <= 128) HMX_RS(64, 2);
+    else if (n_cand <= 256) HMX_RS(64, 4);
+    else if (n_cand <= 1024) HMX_RS(256, 4);
+    else HMX_RS(256, 16);
+#undef HMX_RS
+}
+
+int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, const uint16_t* table_bf16,
+             const float* max_row_norm, int64_t n_rows, int64_t d, int64_t k, const int64_t* exclude, int64_t n_excl,
+             int64_t id_offset, int64_t* out_ids, float* out_scores, int32_t* uncertain, void* workspace,
+             size_t workspace_bytes, hipStream_t s) {
+    if (n_q == 0) return HMX_OK;
+    Plan pl;
+    if (!make_plan(n_q, n_rows, d, k, bf16, pl)) return HMX_EINVAL;
+    if (!queries || !table || !out_ids || !out_scores || !workspace) return HMX_EINVAL;
+    if (bf16 && (!table_bf16 || !max_row_norm || !uncertain)) return HMX_EINVAL;
+    if (exclude == nullptr) n_excl = 0;
+    if (workspace_bytes < pl.total()) return HMX_EWORKSPACE;
+    HmxCarver ws(workspace);
+    uint16_t* q_bf16 = bf16 ? ws.take<uint16_t>((size_t)pl.chunk * pl.dpad) : nullptr;
+    uint2* cand = ws.take<uint2>(pl.cand_bytes / sizeof(uint2));
+    int* meta_cnt = ws.take<int>(pl.meta_bytes / 4);
+    float* meta_thr = ws.take<float>(pl.meta_bytes / 4);
+    const int64_t qpw = 32 * pl.NB;
+
+    for (int64_t q0 = 0; q0 < n_q; q0 += pl.chunk) {
+        const int64_t nq = std::min(pl.chunk, n_q - q0);
+        const int n_qtiles = (int)hmx_ceil_div(nq, qpw);
+        const int waves = n_qtiles * pl.n_splits;
+        CoarseParams p{};
+        p.q_bf16 = q_bf16;
+        p.t_bf16 = table_bf16;
+        p.q_f32 = queries + q0 * d;
+        p.t_f32 = table;
+        p.n_q = nq;
+        p.n_rows = n_rows;
+        p.d = (int)d;
+        p.dpad = pl.dpad;
+        p.n_qtiles = n_qtiles;
+        p.n_splits = pl.n_splits;
+        p.rows_per_split = pl.rows_per_split;
+        p.exclude = exclude ? exclude + q0 * n_excl : nullptr;
+        p.n_excl = (int)n_excl;
+        p.id_offset = id_offset;
+        p.cand = cand;
+        p.meta_cnt = meta_cnt;
+        p.meta_thr = meta_thr;
+        const bool excl = exclude != nullptr && n_excl > 0;
+        if (bf16) {
+            const int64_t rows_pad = (int64_t)n_qtiles * qpw;
+            hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)hmx_ceil_div(rows_pad * 16, 256)), dim3(256), 0, s,
+                               queries + q0 * d, nq, (int)d, rows_pad, pl.dpad, q_bf16, (unsigned*)nullptr);
+            if (pl.NB == 4) launch_bf16_ks<4>(p, waves, pl.KS, pl.KP, excl, s);
+            else if (pl.NB == 2) launch_bf16_ks<2>(p, waves, pl.KS, pl.KP, excl, s);
+            else launch_bf16_ks<1>(p, waves, pl.KS, pl.KP, excl, s);
+        } else {
+            if (pl.KP == 32) {
+                if (excl) hipLaunchKernelGGL((coarse_f32_kernel<32, true>), dim3(waves), dim3(64), 0, s, p);
+                else hipLaunchKernelGGL((coarse_f32_kernel<32, false>), dim3(waves), dim3(64), 0, s, p);
+            } else {
+                if (excl) hipLaunchKernelGGL((coarse_f32_kernel<64, true>), dim3(waves), dim3(64), 0, s, p);
+                else hipLaunchKernelGGL((coarse_f32_kernel<64, false>), dim3(waves), dim3(64), 0, s, p);
+            }
+        }
+        HMX_CHECK_LAUNCH();
+        RescoreParams r{};
+        r.q_f32 = queries + q0 * d;
+        r.t_f32 = table;
+        r.n_q = nq;
+        r.n_rows = n_rows;
+        r.d = (int)d;
+        r.NB = pl.NB;
+        r.KP = pl.KP;
+        r.n_splits = pl.n_splits;
+        r.cand = cand;
+        r.meta_cnt = meta_cnt;
+        r.meta_thr = meta_thr;
+        r.k = (int)k;
+        r.id_offset = id_offset;
+        r.max_row_norm = bf16 ? max_row_norm : nullptr;
+        r.out_ids = out_ids + q0 * k;
+        r.out_scores = out_scores + q0 * k;
+        r.uncertain = uncertain ? uncertain + q0 : nullptr;
+        launch_rescore(r, s);
+        HMX_CHECK_LAUNCH();
+    }
+    return HMX_OK;
+}
+
+}  // namespace
+
+extern "C" int hmx_table_prepare_bf16(const float* table, int64_t n_rows, int64_t d, uint16_t* table_bf16,
+                                      float* max_row_norm, void* stream) {
+    if (!table || !table_bf16 || !max_row_norm || n_rows <= 0 || d <= 0 || d > 128) return HMX_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(max_row_norm, 0, sizeof(float), s) != hipSuccess) return HMX_ELAUNCH;
+    hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)hmx_ceil_div(n_rows * 16, 256)), dim3(256), 0, s, table,
+                       n_rows, (int)d, n_rows, dpad_for(d), table_bf16, reinterpret_cast<unsigned*>(max_row_norm));
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" size_t hmx_score_topk_workspace_bytes(int64_t n_q, int64_t n_rows, int64_t d, int64_t k) {
+    Plan a, b;
+    size_t need = 1024;
+    if (make_plan(n_q, n_rows, d, k, true, a)) need = std::max(need, a.total());
+    if (make_plan(n_q, n_rows, d, k, false, b)) need = std::max(need, b.total());
+    return need;
+}
+
+extern "C" int hmx_score_topk_f32(const float* queries, int64_t n_q, const float* table, int64_t n_rows, int64_t d,
+                                  int64_t k, const int64_t* exclude, int64_t n_excl, int64_t id_offset,
+                                  int64_t* out_ids, float* out_scores, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    return run_topk(false, queries, n_q, table, nullptr, nullptr, n_rows, d, k, exclude, n_excl, id_offset, out_ids,
+                    out_scores, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int hmx_score_topk_bf16(const float* queries, int64_t n_q, const float* table, const uint16_t* table_bf16,
+                                   const float* max_row_norm, int64_t n_rows, int64_t d, int64_t k,
+                                   const int64_t* exclude, int64_t n_excl, int64_t id_offset, int64_t* out_ids,
+                                   float* out_scores, int32_t* uncertain, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    return run_topk(true, queries, n_q, table, table_bf16, max_row_norm, n_rows, d, k, exclude, n_excl, id_offset,
+                    out_ids, out_scores, uncertain, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_shards, int64_t n_q,
+                              int64_t k, int64_t* out_ids, float* out_scores, void* stream) {
+    if (n_q == 0) return HMX_OK;
+    if (!cand_ids || !cand_scores || !out_ids || !out_scores || n_shards <= 0 || k <= 0 || n_shards * k > 1024)
+        return HMX_EINVAL;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)n_q), dim3(64), 0, (hipStream_t)stream, cand_ids, cand_scores,
+                       (int)n_shards, n_q, (int)k, out_ids, out_scores);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}

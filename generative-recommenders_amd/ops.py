@@ -113,3 +113,91 @@ class _GatherRouted(torch.autograd.Function):
 def gather_routed(item_weight, user_weight, ids, token_type):
     """embedding.py:436-450: item rows where token_type==1, user rows where ==2, zeros elsewhere."""
     return _GatherRouted.apply(item_weight, user_weight, ids, token_type)
+
+
+# --------------------------------------------------------------------------- scoring + top-K
+def _dpad(d):
+    p = 16
+    while p < d:
+        p *= 2
+    return p
+
+
+class PreparedTable:
+    """bf16 copy (row stride = next power of two >= max(16, d)) and largest row norm of an fp32
+    table shard, as the bf16 coarse scoring pass needs them.  Re-run refresh() after the table's
+    weights change."""
+
+    def __init__(self, table):
+        _need_cuda(table)
+        self.table = _f32c(table)
+        n, d = self.table.shape
+        if d > 128:
+            raise hmx.HmxError("bf16 coarse scoring supports d <= 128")
+        self.bf16 = torch.empty(n, _dpad(d), dtype=torch.int16, device=table.device)
+        self.max_row_norm = torch.zeros(1, dtype=torch.float32, device=table.device)
+        self.refresh()
+
+    def refresh(self, table=None):
+        if table is not None:
+            self.table = _f32c(table)
+        n, d = self.table.shape
+        hmx.check(hmx.lib().hmx_table_prepare_bf16(hmx.ptr(self.table), n, d, hmx.ptr(self.bf16),
+                                                   hmx.ptr(self.max_row_norm), hmx.current_stream()),
+                  "hmx_table_prepare_bf16")
+        return self
+
+
+def score_topk_exact(queries, table, k, exclude=None, id_offset=0):
+    """Exact top-k by inner product (fp32 MFMA, fma-chain order; score desc then id asc)."""
+    _need_cuda(queries, table, exclude)
+    q, t = _f32c(queries), _f32c(table)
+    nq, d = q.shape
+    ex = _i64c(exclude) if exclude is not None else None
+    ids = torch.empty(nq, k, dtype=torch.int64, device=q.device)
+    sc = torch.empty(nq, k, dtype=torch.float32, device=q.device)
+    L = hmx.lib()
+    ws = workspace(L.hmx_score_topk_workspace_bytes(nq, t.shape[0], d, k), q.device)
+    hmx.check(L.hmx_score_topk_f32(hmx.ptr(q), nq, hmx.ptr(t), t.shape[0], d, k, hmx.ptr(ex),
+                                   0 if ex is None else ex.shape[1], id_offset, hmx.ptr(ids), hmx.ptr(sc),
+                                   hmx.ptr(ws), ws.numel(), hmx.current_stream()), "hmx_score_topk_f32")
+    return ids, sc
+
+
+def score_topk(queries, prepared, k, exclude=None, id_offset=0, return_stats=False):
+    """Top-k by inner product: bf16 MFMA coarse pass + exact re-score, with the exact fp32 kernel
+    re-run for the (rare) queries whose shortlist could not be proven complete.  Same result as
+    score_topk_exact."""
+    _need_cuda(queries, exclude)
+    q = _f32c(queries)
+    t = prepared.table
+    nq, d = q.shape
+    ex = _i64c(exclude) if exclude is not None else None
+    ids = torch.empty(nq, k, dtype=torch.int64, device=q.device)
+    sc = torch.empty(nq, k, dtype=torch.float32, device=q.device)
+    unc = torch.empty(nq, dtype=torch.int32, device=q.device)
+    L = hmx.lib()
+    ws = workspace(L.hmx_score_topk_workspace_bytes(nq, t.shape[0], d, k), q.device)
+    hmx.check(L.hmx_score_topk_bf16(hmx.ptr(q), nq, hmx.ptr(t), hmx.ptr(prepared.bf16), hmx.ptr(prepared.max_row_norm),
+                                    t.shape[0], d, k, hmx.ptr(ex), 0 if ex is None else ex.shape[1], id_offset,
+                                    hmx.ptr(ids), hmx.ptr(sc), hmx.ptr(unc), hmx.ptr(ws), ws.numel(),
+                                    hmx.current_stream()), "hmx_score_topk_bf16")
+    redo = unc.nonzero().flatten()            # host sync: the only one on this path
+    if redo.numel():
+        ids2, sc2 = score_topk_exact(q[redo], t, k, None if ex is None else ex[redo], id_offset)
+        ids[redo], sc[redo] = ids2, sc2
+    if return_stats:
+        return ids, sc, {"uncertain": int(redo.numel())}
+    return ids, sc
+
+
+def topk_merge(cand_ids, cand_scores):
+    """(S, n_q, k) per-shard lists -> global (n_q, k) with the same order / tie-break."""
+    _need_cuda(cand_ids, cand_scores)
+    ci, cs = _i64c(cand_ids), _f32c(cand_scores)
+    S, nq, k = ci.shape
+    ids = torch.empty(nq, k, dtype=torch.int64, device=ci.device)
+    sc = torch.empty(nq, k, dtype=torch.float32, device=ci.device)
+    hmx.check(hmx.lib().hmx_topk_merge(hmx.ptr(ci), hmx.ptr(cs), S, nq, k, hmx.ptr(ids), hmx.ptr(sc),
+                                       hmx.current_stream()), "hmx_topk_merge")
+    return ids, sc

@@ -1,0 +1,128 @@
+"""GPU parity: MFMA scoring + fused top-K through the C ABI vs the C oracle (ids and scores bit-exact),
+plus the reference-captured golden (ids from the reference's torch.mm + torch.topk)."""
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+from generative_recommenders_amd import ops
+from oracle import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _data(nq, rows, d, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(rows, d, generator=g) * scale
+    t[0] = 0
+    q = torch.randn(nq, d, generator=g)
+    return q, t
+
+
+def _check(ids, sc, q, t, k, exclude=None, id_offset=0):
+    want_ids, want_sc = C.score_topk(q.numpy(), t.numpy(), k, None if exclude is None else exclude.numpy(), id_offset)
+    assert np.array_equal(ids.cpu().numpy(), want_ids)
+    assert np.array_equal(sc.cpu().numpy(), want_sc)          # same fma chain => same bits
+
+
+def test_golden_reference_ids_exact_and_bf16():
+    s, p = G.load("g9_topk"), "G9_topk"
+    t, q = G.t(s, p + "/table"), G.t(s, p + "/users")
+    excl = torch.cat([G.t(s, p + "/pos"), G.t(s, p + "/hist")], dim=1)
+    for fn in (lambda *a, **k: ops.score_topk_exact(a[0], a[1], *a[2:], **k),
+               lambda *a, **k: ops.score_topk(a[0], ops.PreparedTable(a[1]), *a[2:], **k)):
+        ids10, sc10 = fn(q.to(DEV), t.to(DEV), 10)
+        assert torch.equal(ids10.cpu(), G.t(s, p + "/ids10"))
+        torch.testing.assert_close(sc10.cpu(), G.t(s, p + "/val10"), rtol=1e-5, atol=1e-5)
+        ids50, _ = fn(q.to(DEV), t.to(DEV), 50, exclude=excl.to(DEV))
+        assert torch.equal(ids50.cpu(), G.t(s, p + "/ids50"))
+
+
+@pytest.mark.parametrize("nq,rows,d,k", [(5, 3000, 16, 10), (70, 20000, 64, 10), (33, 5001, 60, 50), (1, 64, 64, 10),
+                                         (64, 100000, 64, 10), (9, 40000, 128, 50), (40, 777, 6, 3)])
+def test_exact_kernel_matches_oracle(nq, rows, d, k):
+    q, t = _data(nq, rows, d, 100 + nq)
+    ids, sc = ops.score_topk_exact(q.to(DEV), t.to(DEV), k)
+    _check(ids, sc, q, t, k)
+
+
+@pytest.mark.parametrize("nq,rows,d,k", [(5, 3000, 16, 10), (70, 20000, 64, 10), (33, 5001, 60, 50), (1, 64, 64, 10),
+                                         (300, 100000, 64, 10), (9, 40000, 128, 50), (5000, 30000, 64, 10),
+                                         (17000, 9000, 32, 10)])
+def test_bf16_path_matches_oracle(nq, rows, d, k):
+    q, t = _data(nq, rows, d, 200 + nq)
+    ids, sc, st = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), k, return_stats=True)
+    _check(ids, sc, q, t, k)
+    assert st["uncertain"] <= nq // 10 + 1
+
+
+def test_exclusions_and_shard_offset():
+    q, t = _data(40, 30000, 64, 7)
+    g = torch.Generator().manual_seed(8)
+    excl = torch.randint(0, 30000, (40, 30), generator=g) + 1000
+    top = torch.from_numpy(C.score_topk(q.numpy(), t.numpy(), 8, None, 1000)[0])
+    excl[:, :8] = top                                          # knock out the true top-8
+    for fn in (lambda: ops.score_topk_exact(q.to(DEV), t.to(DEV), 50, excl.to(DEV), 1000),
+               lambda: ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), 50, excl.to(DEV), 1000)):
+        ids, sc = fn()
+        _check(ids, sc, q, t, 50, excl, 1000)
+        got = ids.cpu().numpy()
+        assert not any(np.isin(got[i], top[i].numpy()).any() for i in range(got.shape[0]))
+
+
+def test_ties_and_short_tables():
+    t = torch.zeros(40, 16)
+    t[:, 0] = torch.tensor([1, 3, 3, 2, 3, 0] * 6 + [3, 3, 1, 0])
+    q = torch.zeros(3, 16)
+    q[:, 0] = torch.tensor([1.0, 2.0, -1.0])
+    for fn in (lambda k: ops.score_topk_exact(q.to(DEV), t.to(DEV), k),
+               lambda k: ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), k)):
+        for k in (3, 10, 50):                                  # k = 50 > 40 rows: tail is (-1, -inf)
+            ids, sc = fn(k)
+            _check(ids, sc, q, t, k)
+
+
+def test_adversarial_near_duplicates_fall_back_to_exact():
+    """Rows that differ below bf16 resolution: the coarse pass cannot rank them, so the proof must fail and
+    the exact kernel must supply the answer."""
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(1, 64, generator=g)
+    t = base + 1e-4 * torch.randn(4096, 64, generator=g)
+    q = base.repeat(4, 1) + 0.01 * torch.randn(4, 64, generator=g)
+    ids, sc, st = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), 10, return_stats=True)
+    _check(ids, sc, q, t, 10)
+    assert st["uncertain"] > 0
+
+
+def test_merge_matches_unsharded():
+    q, t = _data(50, 30001, 64, 12)
+    full_ids, full_sc = ops.score_topk_exact(q.to(DEV), t.to(DEV), 10)
+    bounds = [0, 7000, 15000, 22222, 30001]
+    parts = [ops.score_topk(q.to(DEV), ops.PreparedTable(t[a:b].to(DEV)), 10, id_offset=a)
+             for a, b in zip(bounds[:-1], bounds[1:])]
+    ids, sc = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(ids, full_ids) and torch.equal(sc, full_sc)
+    want_ids, want_sc = C.topk_merge(torch.stack([p[0] for p in parts]).cpu().numpy(),
+                                     torch.stack([p[1] for p in parts]).cpu().numpy())
+    assert np.array_equal(ids.cpu().numpy(), want_ids) and np.array_equal(sc.cpu().numpy(), want_sc)
+
+
+def test_full_size_properties():
+    """4M x 64 table: (1) bf16 path == exact kernel on 256 queries; (2) a query equal to a scaled table row ranks
+    that row first; (3) returned scores are sorted and re-computable."""
+    rows, d = 4_000_001, 64
+    g = torch.Generator(device=DEV).manual_seed(13)
+    t = torch.randn(rows, d, device=DEV, generator=g)
+    t[0] = 0
+    prep = ops.PreparedTable(t)
+    q = torch.randn(256, d, device=DEV, generator=g)
+    planted = torch.randint(1, rows, (256,), device=DEV, generator=g)
+    q[:128] = t[planted[:128]] * 3.0
+    ids, sc, st = ops.score_topk(q, prep, 10, return_stats=True)
+    ids_e, sc_e = ops.score_topk_exact(q, t, 10)
+    assert torch.equal(ids, ids_e) and torch.equal(sc, sc_e)
+    assert torch.equal(ids[:128, 0], planted[:128])
+    assert torch.all(sc[:, :-1] >= sc[:, 1:])
+    torch.testing.assert_close(sc, (q[:, None, :] * t[ids]).sum(-1), rtol=1e-4, atol=1e-4)
+    assert st["uncertain"] == 0
