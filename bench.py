@@ -1,0 +1,161 @@
+"""Benchmark of the Hydra hot path on MI355X.  One JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload retrieval|train]
+
+Workloads (synthetic data, shapes from BASELINE.json):
+  retrieval  top-10 over a 4,000,001 x 64 item table for 1,000,000 user embeddings per step.
+             N > 1: the table is sharded by contiguous item-id range (one shard per GPU), every
+             rank scores all queries against its shard, per-shard lists are exchanged by RCCL
+             all_gather and merged (strong scaling: the work per step is fixed).
+  train      hydra3 train step (forward + backward + clip + AdamW), batch 1024 x seq 100, d 64.
+A "step" is one pass of the hot path over one batch; inputs are resident in HBM before timing.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("HMX_BENCH_WORKLOAD", "auto"))
+    ap.add_argument("--queries", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=4_000_000)
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--seq-len", type=int, default=100)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def setup_dist(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return world, rank, local
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world):
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline_retrieval(table_host, d, k, seconds_target=10.0):
+    """The reference's own CPU ops for this path (torch.mm + torch.topk, hydra3.py:993,1006, restated in the
+    oracle) on this box's host cores, on a bounded sample of the same workload: batches of 128 queries."""
+    from oracle import hydra_oracle as O
+    threads = torch.get_num_threads()
+    table = torch.from_numpy(table_host)
+    g = torch.Generator().manual_seed(7)
+    n_done, t0 = 0, time.time()
+    while True:
+        q = torch.randn(128, d, generator=g)
+        O.mine_hard_negatives_similarity(q, table, k)
+        n_done += 128
+        dt = time.time() - t0
+        if dt > seconds_target or n_done >= 128 * 64:
+            break
+    return {"value": n_done / dt, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{n_done} queries (batches of 128) x {table.shape[0]} items, d={d}, top-{k}, "
+                      f"torch.mm+topk fp32 on {threads} threads ({dt:.1f} s)"}
+
+
+def run_retrieval(args, world, rank):
+    from generative_recommenders_amd import hmx, synth
+    from generative_recommenders_amd.retrieval import ShardedRetriever, shard_bounds
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n_rows, d, k = args.items + 1, args.dim, 10
+    lo, hi = shard_bounds(n_rows, world, rank)
+    # every rank draws the same full table from one seed and keeps its rows: identical to the unsharded run
+    full = synth.item_table(args.items, d, dev)
+    shard = full[lo:hi].clone()
+    table_host = full.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    del full
+    torch.cuda.empty_cache()
+    q = synth.queries(args.queries, d, dev)
+    retr = ShardedRetriever(shard, id_offset=lo)
+    for _ in range(args.warmup):
+        retr.search(q, k)
+    hmx.profile_enable(True)
+    hmx.profile_collect("topk_coarse_bf16")
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    uncertain = 0
+    for _ in range(args.steps):
+        ids, sc = retr.search(q, k)
+        uncertain += retr.last_stats.get("uncertain", 0)
+    barrier_sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    k_ms, k_launches = hmx.profile_collect("topk_coarse_bf16")
+    hmx.profile_enable(False)
+    assert ids.shape == (args.queries, k) and bool((ids[:, 0] >= 0).all())
+    step_s = elapsed / args.steps
+    # dominant kernel: bf16 MFMA coarse scoring.  Algorithmic flops per launch = 2 * queries * rows * d.
+    flops_per_step = 2.0 * args.queries * (hi - lo) * d
+    achieved = flops_per_step * args.steps / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    out = {
+        "metric": "top-10 queries/s over 4M items", "value": args.queries / step_s, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "infer.py top-10 retrieval, 1M synthetic users x 4M items (configs[2]; sharded = configs[3])",
+                   "queries": args.queries, "items": n_rows, "d": d, "k": k,
+                   "parallelism": f"item-range shards x{world}, all_gather merge" if world > 1 else "single GPU"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "coarse_bf16_kernel", "launches": k_launches,
+                     "avg_launch_ms": k_ms / max(k_launches, 1)},
+        "uncertain_queries_rerun_exact": uncertain,
+    }
+    if table_host is not None:
+        out["cpu_baseline"] = cpu_baseline_retrieval(table_host, d, k)
+    return out
+
+
+def main():
+    args = parse()
+    world, rank, _ = setup_dist(args.gpus)
+    workload = args.workload
+    if workload == "auto":
+        workload = "retrieval"
+    if workload == "train":
+        from bench_train import run_train
+        out = run_train(args, world, rank)
+    else:
+        out = run_retrieval(args, world, rank)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,883 @@
+// Kernels of the Hydra sequence encoder (forward and backward).
+//
+// Activations are (T = B*L tokens, C features) row-major fp32 in HBM.  Dense projections run on
+// bf16 MFMA (32x32x16, fp32 accumulate) with the weight panel staged once per workgroup in LDS;
+// weight gradients run on fp32 MFMA (32x32x2), whose operands load coalesced with the token
+// index on the MFMA K axis.  The selective scan keeps its (N = 16)-wide state per channel in
+// registers and walks the sequence; everything pointwise (SiLU, RoPE, gates, conv, RMSNorm) is
+// fused into a handful of streaming kernels.
+#include <algorithm>
+
+#include "hmx_common.h"
+
+namespace {
+
+using short8 = __attribute__((ext_vector_type(8))) short;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kN = 16;   // SSM state size   (d_state, hydra3.py:593)
+constexpr int kR = 16;   // dt rank          (dt_rank, hydra3.py:591)
+constexpr int kP = kR + 2 * kN;
+constexpr int kMaxGrid = 4096;
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_(float x) { return x * sigmoid_(x); }
+__device__ __forceinline__ float silu_grad_(float x) {
+    const float s = sigmoid_(x);
+    return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float softplus_(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+
+inline int grid_for(int64_t work, int per_block) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(work, per_block), kMaxGrid));
+}
+
+// ---------------------------------------------------------------------------- RMSNorm
+// y = x / sqrt(mean(x^2) + eps) * scale      (hydra3.py:221-229; eps inside the root)
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          int64_t T, int d, float eps, float* __restrict__ y,
+                                                          float* __restrict__ rstd) {
+    const int l = threadIdx.x & 15;
+    for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < hmx_ceil_div(T, 16) * 16;
+         row += (int64_t)gridDim.x * 16) {
+        const bool ok = row < T;
+        float ss = 0.f;
+        if (ok)
+            for (int c = l; c < d; c += 16) {
+                const float v = x[row * d + c];
+                ss += v * v;
+            }
+        for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        const float r = 1.f / sqrtf(ss / (float)d + eps);
+        if (ok) {
+            for (int c = l; c < d; c += 16) y[row * d + c] = x[row * d + c] * r * scale[c];
+            if (l == 0 && rstd) rstd[row] = r;
+        }
+    }
+}
+
+// dx_j = r * (s_j dy_j - x_j r^2 mean_i(dy_i s_i x_i));  dscale_j = sum_t dy_j x_j r  (per-block partials)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ rstd, const float* __restrict__ dy,
+                                                          int64_t T, int d, float* __restrict__ dx,
+                                                          float* __restrict__ dscale_part) {
+    __shared__ float red[16][257];
+    const int l = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    float ds[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ds[i] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 16 + slot; row < hmx_ceil_div(T, 16) * 16; row += (int64_t)gridDim.x * 16) {
+        const bool ok = row < T;
+        float dot = 0.f;
+        if (ok)
+            for (int c = l; c < d; c += 16) dot += dy[row * d + c] * scale[c] * x[row * d + c];
+        for (int off = 8; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        if (ok) {
+            const float r = rstd[row];
+            const float coef = dot * r * r / (float)d;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = l + 16 * i;
+                if (c < d) {
+                    const float xv = x[row * d + c], g = dy[row * d + c];
+                    dx[row * d + c] = r * (scale[c] * g - xv * coef);
+                    ds[i] += g * xv * r;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = l + 16 * i;
+        if (c < d) red[slot][c] = ds[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][c];
+        dscale_part[(int64_t)blockIdx.x * d + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------- column sums
+// out[c] = sum_r P[r * ld + c], rows summed in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ P, int64_t rows, int64_t cols, int64_t ld,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < cols)
+        for (int64_t r = w; r < rows; r += 4) s += P[r * ld + c];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// ---------------------------------------------------------------------------- linear (bf16 MFMA)
+struct LinearParams {
+    const float* X;
+    int64_t ldx;
+    const float* W;          // viewed as Wv(n, k) = W[n * w_rs + k * w_cs]
+    int64_t w_rs, w_cs;
+    const float* bias;       // (N) or null
+    int64_t T;
+    int N, K, n_chunk;
+    float* Y;
+    int64_t ldy;
+    const float* R1;         // residual 1: Y += c1 * R1
+    int64_t ldr1;
+    float c1;
+    const float* R2;
+    int64_t ldr2;
+    float c2;
+    const float* in_rowmask;   // (T) or null: X row scaled before the product
+    const float* out_rowmask;  // (T) or null: Y row scaled after everything else
+    int accumulate;            // Y = Y_old + result
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void linear_kernel(LinearParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KP = KS * 16 + 8;  // bf16 elements per LDS row (+8 keeps ds_read_b128 conflict-free)
+    uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    const int n_base = blockIdx.y * p.n_chunk;
+    const int nc = min(p.n_chunk, p.N - n_base);
+    const int npad = (nc + 31) / 32 * 32;
+    for (int idx = threadIdx.x; idx < npad * KS * 16; idx += 256) {
+        const int n = idx / (KS * 16), k = idx % (KS * 16);
+        const float v = (n < nc && k < p.K) ? p.W[(int64_t)(n_base + n) * p.w_rs + (int64_t)k * p.w_cs] : 0.f;
+        wl[n * KP + k] = hmx_f32_to_bf16(v);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = hmx_ceil_div(p.T, 32);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t t = tile * 32 + i;
+        const bool ok = t < p.T;
+        const float im = (ok && p.in_rowmask) ? p.in_rowmask[t] : 1.f;
+        const float* xr = p.X + (ok ? t : 0) * p.ldx;
+        short8 a[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = 16 * ks + 8 * h;
+            float v[8];
+            if (ok && k0 + 8 <= p.K && ((reinterpret_cast<uintptr_t>(xr + k0) & 15) == 0)) {
+                const float4 lo = *reinterpret_cast<const float4*>(xr + k0);
+                const float4 hi = *reinterpret_cast<const float4*>(xr + k0 + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+                v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (ok && k0 + e < p.K) ? xr[k0 + e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[ks][e] = (short)hmx_f32_to_bf16(v[e] * im);
+        }
+        for (int nt = 0; nt < npad / 32; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const short8 b = *reinterpret_cast<const short8*>(wl + (nt * 32 + i) * KP + 16 * ks + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b, acc, 0, 0, 0);
+            }
+            const int n = n_base + nt * 32 + i;
+            if (n < n_base + nc) {
+                const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t tt = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (tt < p.T) {
+                        float v = acc[r] + bv;
+                        if (p.R1) v += p.c1 * p.R1[tt * p.ldr1 + n];
+                        if (p.R2) v += p.c2 * p.R2[tt * p.ldr2 + n];
+                        if (p.out_rowmask) v *= p.out_rowmask[tt];
+                        float* dst = p.Y + tt * p.ldy + n;
+                        if (p.accumulate) v += *dst;
+                        *dst = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- weight gradient (fp32 MFMA)
+// part[s][n][k] = sum_{t in split s} dY[t][n] * X[t][k] * in_rowmask[t];  column K (if with_bias) = sum_t dY[t][n].
+struct WgradParams {
+    const float* dY;
+    int64_t ldy;
+    const float* X;
+    int64_t ldx;
+    const float* in_rowmask;
+    int64_t T, tok_per_split;
+    int N, K, with_bias;
+    float* part;
+};
+
+__global__ __launch_bounds__(64) void wgrad_kernel(WgradParams p) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int kx = p.K + (p.with_bias ? 1 : 0);
+    const int kt_n = (kx + 31) / 32;
+    const int nt = blockIdx.y / kt_n, kt = blockIdx.y % kt_n;
+    const int n = nt * 32 + i, kc = kt * 32 + i;
+    const int64_t t0 = (int64_t)blockIdx.x * p.tok_per_split;
+    const int64_t t1 = min(p.T, t0 + p.tok_per_split);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool n_ok = n < p.N;
+    const int kind = kc < p.K ? 0 : ((kc == p.K && p.with_bias) ? 1 : 2);
+    for (int64_t t = t0; t < t1; t += 2) {
+        const int64_t tt = t + h;
+        const bool ok = tt < t1;
+        const float a = (ok && n_ok) ? p.dY[tt * p.ldy + n] : 0.f;
+        float b = 0.f;
+        if (ok) {
+            if (kind == 0) {
+                b = p.X[tt * p.ldx + kc];
+                if (p.in_rowmask) b *= p.in_rowmask[tt];
+            } else if (kind == 1) {
+                b = 1.f;
+            }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (kc < kx) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nr = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (nr < p.N) p.part[((int64_t)blockIdx.x * p.N + nr) * kx + kc] = acc[r];
+        }
+    }
+}
+
+// dW[n * ldw + k] = sum_s part[s][n][k];  db[n] = sum_s part[s][n][K]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int n_splits, int N, int K,
+                                                           int kx, float* __restrict__ dW, int64_t ldw,
+                                                           float* __restrict__ db) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * kx) return;
+    const int n = idx / kx, k = idx % kx;
+    float s = 0.f;
+    for (int sp = 0; sp < n_splits; ++sp) s += part[((int64_t)sp * N + n) * kx + k];
+    if (k < K) dW[(int64_t)n * ldw + k] = s;
+    else if (db) db[n] = s;
+}
+
+// ---------------------------------------------------------------------------- pointwise kernels
+// s = SiLU(x1);  y2 = RoPE(s) on interleaved pairs, angle tables (L, hd/2)   (hydra3.py:368-386)
+__global__ __launch_bounds__(256) void silu_rope_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ cs,
+                                                            const float* __restrict__ sn, int64_t T, int L, int d,
+                                                            int hd, float* __restrict__ s, float* __restrict__ y2) {
+    const int64_t total = T * (d / 2);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t t = idx / (d / 2);
+        const int pp = (int)(idx % (d / 2)), ip = pp % (hd / 2), pos = (int)(t % L);
+        const float c = cs[pos * (hd / 2) + ip], sv = sn[pos * (hd / 2) + ip];
+        const float2 xv = *reinterpret_cast<const float2*>(x1 + t * d + 2 * pp);
+        const float se = silu_(xv.x), so = silu_(xv.y);
+        *reinterpret_cast<float2*>(s + t * d + 2 * pp) = make_float2(se, so);
+        *reinterpret_cast<float2*>(y2 + t * d + 2 * pp) = make_float2(se * c - so * sv, se * sv + so * c);
+    }
+}
+
+// dx1 = (ds + RoPE^T(dy2)) * SiLU'(x1)
+__global__ __launch_bounds__(256) void silu_rope_bwd_kernel(const float* __restrict__ x1, const float* __restrict__ cs,
+                                                            const float* __restrict__ sn, const float* __restrict__ ds,
+                                                            const float* __restrict__ dy2, int64_t T, int L, int d,
+                                                            int hd, float* __restrict__ dx1) {
+    const int64_t total = T * (d / 2);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t t = idx / (d / 2);
+        const int pp = (int)(idx % (d / 2)), ip = pp % (hd / 2), pos = (int)(t % L);
+        const float c = cs[pos * (hd / 2) + ip], sv = sn[pos * (hd / 2) + ip];
+        const float2 xv = *reinterpret_cast<const float2*>(x1 + t * d + 2 * pp);
+        const float2 g1 = *reinterpret_cast<const float2*>(ds + t * d + 2 * pp);
+        const float2 g2 = *reinterpret_cast<const float2*>(dy2 + t * d + 2 * pp);
+        const float ge = g1.x + g2.x * c + g2.y * sv;
+        const float go = g1.y - g2.x * sv + g2.y * c;
+        *reinterpret_cast<float2*>(dx1 + t * d + 2 * pp) = make_float2(ge * silu_grad_(xv.x), go * silu_grad_(xv.y));
+    }
+}
+
+// mode 0: out = a * b * c                      (y1 * y2 / sqrt(H),           hydra3.py:387)
+// mode 1: out = SiLU(a) * b                    (SwiGLU gate,                 hydra3.py:416-418)
+__global__ __launch_bounds__(256) void binary_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         int64_t n, float c, int mode, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = mode == 0 ? a[i] * b[i] * c : silu_(a[i]) * b[i];
+}
+
+__global__ __launch_bounds__(256) void binary_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ g, int64_t n, float c, int mode,
+                                                         float* __restrict__ da, float* __restrict__ db) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (mode == 0) {
+            da[i] = g[i] * b[i] * c;
+            db[i] = g[i] * a[i] * c;
+        } else {
+            da[i] = g[i] * b[i] * silu_grad_(a[i]);
+            db[i] = g[i] * silu_(a[i]);
+        }
+    }
+}
+
+// out[t, :] = (c0 X0 + c1 X1 + c2 X2 + c3 X3)[t, :] * rowmask[t]   (null inputs are skipped)
+__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                      const float* __restrict__ x2, const float* __restrict__ x3,
+                                                      float c0, float c1, float c2, float c3,
+                                                      const float* __restrict__ rowmask, int64_t T, int d,
+                                                      float* __restrict__ out) {
+    const int64_t n = T * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = c0 * x0[i];
+        if (x1) v += c1 * x1[i];
+        if (x2) v += c2 * x2[i];
+        if (x3) v += c3 * x3[i];
+        if (rowmask) v *= rowmask[i / d];
+        out[i] = v;
+    }
+}
+
+// Index preparation of log2feats (hydra3.py:621-659): padding mask, position ids, time-interval bins.
+__global__ __launch_bounds__(256) void seq_index_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ ts,
+                                                        int64_t T, int L, int time_span, float* __restrict__ mask,
+                                                        int64_t* __restrict__ pos_idx, int64_t* __restrict__ time_bin) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T; t += (int64_t)gridDim.x * 256) {
+        const int l = (int)(t % L);
+        const bool valid = ids[t] != 0;
+        mask[t] = valid ? 1.f : 0.f;
+        pos_idx[t] = valid ? l + 1 : 0;
+        int64_t dt = 0;
+        if (l > 0 && ids[t - 1] != 0) dt = ts[t] - ts[t - 1];
+        int64_t bin = (int64_t)logf((float)dt + 1.0f);
+        bin = bin > time_span - 1 ? time_span - 1 : bin;
+        time_bin[t] = valid ? bin : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------- causal depthwise conv + SiLU
+// x: (T, C).  xc[t, c] = SiLU(b[c] + sum_j w[c][j] x[t-3+j, c]) with taps before the sequence start reading
+// zero   (hydra3.py:243-250, 266-269).
+__global__ __launch_bounds__(256) void conv_silu_fwd_kernel(const float* __restrict__ xz, const float* __restrict__ w,
+                                                            const float* __restrict__ b, int64_t T, int L, int C,
+                                                            float* __restrict__ xc) {
+    const int64_t n = T * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int64_t t = idx / C;
+        const int c = (int)(idx % C), pos = (int)(t % L);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tp = pos - 3 + j;
+            if (tp >= 0) acc += w[c * 4 + j] * xz[(t - 3 + j) * C + c];
+        }
+        xc[idx] = silu_(b[c] + acc);
+    }
+}
+
+// One block per (sequence, 256-channel slab); walks the sequence backwards with sliding windows.
+// Writes dx (T, C) and per-sequence partials part[b][c][5] = (dw0..dw3, db).
+__global__ __launch_bounds__(256) void conv_silu_bwd_kernel(const float* __restrict__ xz, const float* __restrict__ w,
+                                                            const float* __restrict__ b, const float* __restrict__ dxc,
+                                                            int L, int C, float* __restrict__ dxz,
+                                                            float* __restrict__ part) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t seq = blockIdx.x;
+    const float w0 = w[c * 4], w1 = w[c * 4 + 1], w2 = w[c * 4 + 2], w3 = w[c * 4 + 3], bb = b[c];
+    const float* xs = xz + seq * L * C + c;
+    auto X = [&](int t) { return t >= 0 ? xs[(int64_t)t * C] : 0.f; };
+    float x0 = X(L - 4), x1 = X(L - 3), x2 = X(L - 2), x3 = X(L - 1);  // x[t-3..t]
+    float du1 = 0.f, du2 = 0.f, du3 = 0.f;                             // du[t+1..t+3]
+    float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f, dw3 = 0.f, db = 0.f;
+    for (int t = L - 1; t >= 0; --t) {
+        const float u = bb + (((w0 * x0) + w1 * x1) + w2 * x2) + w3 * x3;
+        const float du = dxc[(seq * L + t) * C + c] * silu_grad_(u);
+        dw0 += du * x0; dw1 += du * x1; dw2 += du * x2; dw3 += du * x3;
+        db += du;
+        dxz[(seq * L + t) * C + c] = w3 * du + w2 * du1 + w1 * du2 + w0 * du3;
+        du3 = du2; du2 = du1; du1 = du;
+        x3 = x2; x2 = x1; x1 = x0; x0 = X(t - 4);
+    }
+    float* o = part + (seq * C + c) * 5;
+    o[0] = dw0; o[1] = dw1; o[2] = dw2; o[3] = dw3; o[4] = db;
+}
+
+// ---------------------------------------------------------------------------- selective scan
+// Per channel c (head hh = c / ED):  delta = softplus(b_dt + W_dt . dr_t),  a = exp(delta * A),
+//   h = a * h + (delta * B_t) * x_t,  y_t = sum_n h[n] C_t[n] + D x_t,  out = y_t * SiLU(z_t)
+// (hydra3.py:107-123, 203-214, 273).  dbc rows (T, H, 48) = [dr(16) | B(16) | C(16)] are staged in LDS.
+struct ScanParams {
+    const float* xc;     // (T, C)
+    const float* xz;     // z gate input, (T, C)
+    const float* dbc;    // (T, H, 48)
+    const float* Wdt;    // (C, 16)
+    const float* bdt;    // (C)
+    const float* A_log;  // (C, 16)
+    const float* D;      // (C)
+    int B, L, C, ED, H;
+    float* yg;           // (T, C)
+    float* hs;           // (T, C, 16) or null (states kept for the backward pass)
+};
+
+constexpr int kScanChunk = 64;  // time steps of dbc staged per LDS fill
+
+__global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rows = reinterpret_cast<float*>(smem);  // [kScanChunk][H][48]
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const bool live = c < p.C;
+    const int cc = live ? c : 0;
+    const int hh = cc / p.ED, ce = cc % p.ED;
+    const int64_t seq = blockIdx.x;
+    const int HP = p.H * kP;
+    float A[kN], Wd[kR], h[kN];
+#pragma unroll
+    for (int n = 0; n < kN; ++n) {
+        A[n] = -__expf(p.A_log[cc * kN + n]);
+        Wd[n] = p.Wdt[cc * kR + n];
+        h[n] = 0.f;
+    }
+    const float bd = p.bdt[cc], Dv = p.D[cc];
+    for (int tc0 = 0; tc0 < p.L; tc0 += kScanChunk) {
+        const int steps = min(kScanChunk, p.L - tc0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < steps * HP; idx += 256) rows[idx] = p.dbc[(seq * p.L + tc0) * HP + idx];
+        __syncthreads();
+        if (!live) continue;
+        for (int s = 0; s < steps; ++s) {
+            const int64_t row = seq * p.L + tc0 + s;
+            const float x = p.xc[row * p.C + c];
+            const float z = p.xz[row * p.C + c];
+            const float* r = rows + s * HP + hh * kP;
+            float dpre = 0.f;
+#pragma unroll
+            for (int k = 0; k < kR; ++k) dpre += Wd[k] * r[k];
+            const float delta = softplus_(dpre + bd);
+            float y = 0.f;
+#pragma unroll
+            for (int n = 0; n < kN; ++n) {
+                const float a = __expf(delta * A[n]);
+                h[n] = a * h[n] + (delta * r[kR + n]) * x;
+                y += h[n] * r[kR + kN + n];
+            }
+            if (p.hs) {
+                float4* dst = reinterpret_cast<float4*>(p.hs + (row * p.C + c) * kN);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+            }
+            p.yg[row * p.C + c] = (y + Dv * x) * silu_(z);
+        }
+    }
+}
+
+// Sum of v[n] over the G lanes of a channel group, for all 16 n at once, by a halving butterfly:
+// afterwards lane l of the group (with l % (G/16) == 0) holds the total for n = l / (G/16).
+template <int G>
+__device__ __forceinline__ float group_reduce16(const float (&v)[16]) {
+    const int lane = threadIdx.x;
+    float w8[8], w4[4], w2[2], w1;
+    {
+        const bool up = (lane & (G / 2)) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w8[i] = (up ? v[i + 8] : v[i]) + __shfl_xor(up ? v[i] : v[i + 8], G / 2);
+    }
+    {
+        const bool up = (lane & (G / 4)) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4[i] = (up ? w8[i + 4] : w8[i]) + __shfl_xor(up ? w8[i] : w8[i + 4], G / 4);
+    }
+    {
+        const bool up = (lane & (G / 8)) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w2[i] = (up ? w4[i + 2] : w4[i]) + __shfl_xor(up ? w4[i] : w4[i + 2], G / 8);
+    }
+    {
+        const bool up = (lane & (G / 16)) != 0;
+        w1 = (up ? w2[1] : w2[0]) + __shfl_xor(up ? w2[0] : w2[1], G / 16);
+    }
+#pragma unroll
+    for (int off = G / 32; off >= 1; off >>= 1) w1 += __shfl_xor(w1, off);
+    return w1;
+}
+
+struct ScanBwdParams {
+    ScanParams f;          // forward inputs (yg unused); f.hs = saved states
+    const float* dyg;      // (T, C)
+    float* dxc;            // (T, C)
+    float* dxz;            // dz, (T, C)
+    float* ddbc_part;      // (T, H, GPH, 48): per channel-group partial sums of d(dbc)
+    float* par_part;       // (B, C, 34): [dA_log(16) | dWdt(16) | dbdt | dD] per sequence
+    int GPH;               // channel groups per head = ED / G
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void scan_bwd_kernel(ScanBwdParams q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rows = reinterpret_cast<float*>(smem);
+    const ScanParams& p = q.f;
+    const int c = blockIdx.y * 256 + threadIdx.x;   // C is a multiple of G (host-checked), so whole groups are live
+    const bool live = c < p.C;
+    const int cc = live ? c : 0;
+    const int hh = cc / p.ED, ce = cc % p.ED;
+    const int gih = ce / G, lig = ce % G;
+    const int64_t seq = blockIdx.x;
+    const int HP = p.H * kP;
+    float A[kN], Wd[kR], carry[kN], dA[kN], dWd[kR];
+#pragma unroll
+    for (int n = 0; n < kN; ++n) {
+        A[n] = -__expf(p.A_log[cc * kN + n]);
+        Wd[n] = p.Wdt[cc * kR + n];
+        carry[n] = 0.f;
+        dA[n] = 0.f;
+        dWd[n] = 0.f;
+    }
+    const float bd = p.bdt[cc], Dv = p.D[cc];
+    float dbd = 0.f, dD = 0.f;
+    const int n_chunks = (p.L + kScanChunk - 1) / kScanChunk;
+    for (int ch = n_chunks - 1; ch >= 0; --ch) {
+        const int tc0 = ch * kScanChunk;
+        const int steps = min(kScanChunk, p.L - tc0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < steps * HP; idx += 256) rows[idx] = p.dbc[(seq * p.L + tc0) * HP + idx];
+        __syncthreads();
+        if (!live) continue;
+        for (int s = steps - 1; s >= 0; --s) {
+            const int64_t row = seq * p.L + tc0 + s;
+            const float x = p.xc[row * p.C + c];
+            const float z = p.xz[row * p.C + c];
+            const float gy = q.dyg[row * p.C + c];
+            const float* r = rows + s * HP + hh * kP;
+            float hcur[kN];
+            {
+                const float4* src = reinterpret_cast<const float4*>(p.hs + (row * p.C + c) * kN);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 v = src[k4];
+                    hcur[4 * k4] = v.x; hcur[4 * k4 + 1] = v.y; hcur[4 * k4 + 2] = v.z; hcur[4 * k4 + 3] = v.w;
+                }
+            }
+            float dpre = 0.f;
+#pragma unroll
+            for (int k = 0; k < kR; ++k) dpre += Wd[k] * r[k];
+            dpre += bd;
+            const float delta = softplus_(dpre);
+            float y = 0.f;
+#pragma unroll
+            for (int n = 0; n < kN; ++n) y += hcur[n] * r[kR + kN + n];
+            const float ypre = y + Dv * x;
+            const float sz = silu_(z);
+            const float dy = gy * sz;
+            q.dxz[row * p.C + c] = gy * ypre * silu_grad_(z);
+            dD += dy * x;
+            float dx = Dv * dy, ddelta = 0.f;
+            float vB[kN], vC[kN];
+#pragma unroll
+            for (int n = 0; n < kN; ++n) {
+                const float a = __expf(delta * A[n]);
+                const float Bn = r[kR + n];
+                const float g = r[kR + kN + n] * dy + carry[n];   // dL/dh_t[n]
+                carry[n] = a * g;
+                const float bterm = delta * Bn * x;
+                const float hprev_a = hcur[n] - bterm;            // a_t * h_{t-1}
+                ddelta += g * (A[n] * hprev_a + Bn * x);
+                dA[n] += g * delta * hprev_a;
+                dx += g * delta * Bn;
+                vB[n] = g * delta * x;
+                vC[n] = dy * hcur[n];
+            }
+            q.dxc[row * p.C + c] = dx;
+            const float dd = ddelta * (dpre > 20.f ? 1.f : sigmoid_(dpre));
+            dbd += dd;
+            float vR[kR];
+#pragma unroll
+            for (int k = 0; k < kR; ++k) {
+                dWd[k] += dd * r[k];
+                vR[k] = dd * Wd[k];
+            }
+            const float sR = group_reduce16<G>(vR);
+            const float sB = group_reduce16<G>(vB);
+            const float sC = group_reduce16<G>(vC);
+            if ((lig & (G / 16 - 1)) == 0) {
+                const int n = lig / (G / 16);
+                float* o = q.ddbc_part + ((row * p.H + hh) * q.GPH + gih) * kP;
+                o[n] = sR;
+                o[kR + n] = sB;
+                o[kR + kN + n] = sC;
+            }
+        }
+    }
+    if (live) {
+        float* o = q.par_part + (seq * p.C + c) * 34;
+#pragma unroll
+        for (int n = 0; n < kN; ++n) {
+            o[n] = dA[n] * A[n];       // A = -exp(A_log)  =>  dA/dA_log = A
+            o[kN + n] = dWd[n];
+        }
+        o[32] = dbd;
+        o[33] = dD;
+    }
+}
+
+// out[r][j] = sum_g part[r][g][j]  (fixed order)
+__global__ __launch_bounds__(256) void sum_groups_kernel(const float* __restrict__ part, int64_t rows, int groups, int w,
+                                                         float* __restrict__ out) {
+    const int64_t n = rows * w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / w;
+        const int j = (int)(i % w);
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += part[(r * groups + g) * w + j];
+        out[i] = s;
+    }
+}
+
+int ks_for(int K) {
+    int ks = 1;
+    while (ks * 16 < K) ks *= 2;
+    return ks;
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" int hmx_rmsnorm_fwd(const float* x, const float* scale, int64_t T, int64_t d, float eps, float* y,
+                               float* rstd, void* stream) {
+    HMX_ENTER();
+    if (T == 0) return HMX_OK;
+    if (!x || !scale || !y || d <= 0 || d > 256) return HMX_EINVAL;
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid_for(T, 16)), dim3(256), 0, (hipStream_t)stream, x, scale, T, (int)d,
+                       eps, y, rstd);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int64_t hmx_rmsnorm_bwd_blocks(int64_t T) { return std::min<int64_t>(std::max<int64_t>(1, hmx_ceil_div(T, 16)), 512); }
+
+extern "C" int hmx_rmsnorm_bwd(const float* x, const float* scale, const float* rstd, const float* dy, int64_t T,
+                               int64_t d, float* dx, float* dscale_part, void* stream) {
+    HMX_ENTER();
+    if (T == 0) return HMX_OK;
+    if (!x || !scale || !rstd || !dy || !dx || !dscale_part || d <= 0 || d > 256) return HMX_EINVAL;
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((int)hmx_rmsnorm_bwd_blocks(T)), dim3(256), 0, (hipStream_t)stream, x,
+                       scale, rstd, dy, T, (int)d, dx, dscale_part);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_t ld, float* out, void* stream) {
+    HMX_ENTER();
+    if (cols == 0) return HMX_OK;
+    if (!P || !out || rows < 0 || ld < cols) return HMX_EINVAL;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)hmx_ceil_div(cols, 64)), dim3(256), 0, (hipStream_t)stream, P, rows,
+                       cols, ld, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, int64_t w_cs,
+                              const float* bias, int64_t T, int64_t N, int64_t K, float* Y, int64_t ldy,
+                              const float* R1, int64_t ldr1, float c1, const float* R2, int64_t ldr2, float c2,
+                              const float* in_rowmask, const float* out_rowmask, int accumulate, void* stream) {
+    HMX_ENTER();
+    if (T == 0 || N == 0) return HMX_OK;
+    if (!X || !W || !Y || K <= 0 || K > 256 || N < 0 || N > 65535) return HMX_EINVAL;
+    LinearParams p{X, ldx, W, w_rs, w_cs, bias, T, (int)N, (int)K, 0, Y, ldy, R1, ldr1, c1, R2, ldr2, c2,
+                   in_rowmask, out_rowmask, accumulate};
+    const int ks = ks_for((int)K);
+    const int kp = ks * 16 + 8;
+    int n_chunk = std::min<int>(256, (60 * 1024 / (kp * 2)) / 32 * 32);
+    n_chunk = std::min<int>(n_chunk, (int)((N + 31) / 32 * 32));
+    p.n_chunk = n_chunk;
+    const size_t lds = (size_t)n_chunk * kp * 2;
+    const dim3 grid((unsigned)std::min<int64_t>(hmx_ceil_div(hmx_ceil_div(T, 32), 4), 1024),
+                    (unsigned)hmx_ceil_div(N, n_chunk));
+    hipStream_t s = (hipStream_t)stream;
+    switch (ks) {
+        case 1: hipLaunchKernelGGL(linear_kernel<1>, grid, dim3(256), lds, s, p); break;
+        case 2: hipLaunchKernelGGL(linear_kernel<2>, grid, dim3(256), lds, s, p); break;
+        case 4: hipLaunchKernelGGL(linear_kernel<4>, grid, dim3(256), lds, s, p); break;
+        case 8: hipLaunchKernelGGL(linear_kernel<8>, grid, dim3(256), lds, s, p); break;
+        default: hipLaunchKernelGGL(linear_kernel<16>, grid, dim3(256), lds, s, p); break;
+    }
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+static int64_t wgrad_splits(int64_t T) { return std::max<int64_t>(1, std::min<int64_t>(256, hmx_ceil_div(T, 256))); }
+
+extern "C" size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K) {
+    return (size_t)wgrad_splits(T) * N * (K + 1) * sizeof(float) + 256;
+}
+
+extern "C" int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, const float* in_rowmask,
+                                    int64_t T, int64_t N, int64_t K, float* dW, int64_t ldw, float* dbias,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    HMX_ENTER();
+    if (N == 0 || K == 0) return HMX_OK;
+    if (!dY || !X || !dW || !workspace || T <= 0) return HMX_EINVAL;
+    if (workspace_bytes < hmx_linear_wgrad_workspace_bytes(T, N, K)) return HMX_EWORKSPACE;
+    const int64_t S = wgrad_splits(T);
+    const int with_bias = dbias != nullptr;
+    const int kx = (int)K + with_bias;
+    int64_t tps = hmx_ceil_div(T, S);
+    tps += tps & 1;
+    WgradParams p{dY, ldy, X, ldx, in_rowmask, T, tps, (int)N, (int)K, with_bias, (float*)workspace};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)S, (unsigned)(hmx_ceil_div(N, 32) * hmx_ceil_div(kx, 32))), dim3(64), 0,
+                       s, p);
+    HMX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)hmx_ceil_div(N * kx, 256)), dim3(256), 0, s,
+                       (const float*)workspace, (int)S, (int)N, (int)K, kx, dW, ldw, dbias);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_silu_rope_fwd(const float* x1, const float* cos_t, const float* sin_t, int64_t T, int64_t L,
+                                 int64_t d, int64_t hd, float* s, float* y2, void* stream) {
+    HMX_ENTER();
+    if (T == 0) return HMX_OK;
+    if (!x1 || !cos_t || !sin_t || !s || !y2 || d % 2 || hd % 2 || d % hd || L <= 0) return HMX_EINVAL;
+    hipLaunchKernelGGL(silu_rope_fwd_kernel, dim3(grid_for(T * d / 2, 256)), dim3(256), 0, (hipStream_t)stream, x1, cos_t,
+                       sin_t, T, (int)L, (int)d, (int)hd, s, y2);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_silu_rope_bwd(const float* x1, const float* cos_t, const float* sin_t, const float* ds,
+                                 const float* dy2, int64_t T, int64_t L, int64_t d, int64_t hd, float* dx1,
+                                 void* stream) {
+    HMX_ENTER();
+    if (T == 0) return HMX_OK;
+    if (!x1 || !cos_t || !sin_t || !ds || !dy2 || !dx1 || d % 2 || hd % 2 || d % hd || L <= 0) return HMX_EINVAL;
+    hipLaunchKernelGGL(silu_rope_bwd_kernel, dim3(grid_for(T * d / 2, 256)), dim3(256), 0, (hipStream_t)stream, x1, cos_t,
+                       sin_t, ds, dy2, T, (int)L, (int)d, (int)hd, dx1);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_binary_fwd(const float* a, const float* b, int64_t n, float c, int mode, float* out, void* stream) {
+    HMX_ENTER();
+    if (n == 0) return HMX_OK;
+    if (!a || !b || !out || mode < 0 || mode > 1) return HMX_EINVAL;
+    hipLaunchKernelGGL(binary_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, c, mode, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_binary_bwd(const float* a, const float* b, const float* g, int64_t n, float c, int mode, float* da,
+                              float* db, void* stream) {
+    HMX_ENTER();
+    if (n == 0) return HMX_OK;
+    if (!a || !b || !g || !da || !db || mode < 0 || mode > 1) return HMX_EINVAL;
+    hipLaunchKernelGGL(binary_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, g, n, c, mode,
+                       da, db);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_combine_f32(const float* x0, const float* x1, const float* x2, const float* x3, float c0, float c1,
+                               float c2, float c3, const float* rowmask, int64_t T, int64_t d, float* out,
+                               void* stream) {
+    HMX_ENTER();
+    if (T == 0) return HMX_OK;
+    if (!x0 || !out || d <= 0) return HMX_EINVAL;
+    hipLaunchKernelGGL(combine_kernel, dim3(grid_for(T * d, 256)), dim3(256), 0, (hipStream_t)stream, x0, x1, x2, x3, c0, c1,
+                       c2, c3, rowmask, T, (int)d, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_seq_index(const int64_t* ids, const int64_t* ts, int64_t T, int64_t L, int64_t time_span, float* mask,
+                             int64_t* pos_idx, int64_t* time_bin, void* stream) {
+    HMX_ENTER();
+    if (T == 0) return HMX_OK;
+    if (!ids || !ts || !mask || !pos_idx || !time_bin || L <= 0 || T % L) return HMX_EINVAL;
+    hipLaunchKernelGGL(seq_index_kernel, dim3(grid_for(T, 256)), dim3(256), 0, (hipStream_t)stream, ids, ts, T, (int)L,
+                       (int)time_span, mask, pos_idx, time_bin);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_conv_silu_fwd(const float* x, const float* w, const float* b, int64_t T, int64_t L, int64_t C,
+                                 float* xc, void* stream) {
+    HMX_ENTER();
+    if (T == 0) return HMX_OK;
+    if (!x || !w || !b || !xc || L <= 0 || T % L || C <= 0) return HMX_EINVAL;
+    hipLaunchKernelGGL(conv_silu_fwd_kernel, dim3(grid_for(T * C, 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, T,
+                       (int)L, (int)C, xc);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_conv_silu_bwd(const float* x, const float* w, const float* b, const float* dxc, int64_t B, int64_t L,
+                                 int64_t C, float* dx, float* part, void* stream) {
+    HMX_ENTER();
+    if (B == 0) return HMX_OK;
+    if (!x || !w || !b || !dxc || !dx || !part || L <= 0 || C <= 0) return HMX_EINVAL;
+    hipLaunchKernelGGL(conv_silu_bwd_kernel, dim3((unsigned)B, (unsigned)hmx_ceil_div(C, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, w, b, dxc, (int)L, (int)C, dx, part);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+static bool scan_shape_ok(int64_t C, int64_t ED, int64_t H) {
+    return ED >= 32 && (ED & (ED - 1)) == 0 && C == ED * H && H * kP * kScanChunk * 4 <= 64 * 1024;
+}
+
+extern "C" int hmx_scan_fwd(const float* xc, const float* xz, const float* dbc, const float* Wdt, const float* bdt,
+                            const float* A_log, const float* D, int64_t B, int64_t L, int64_t C, int64_t ED, int64_t H,
+                            float* yg, float* hs, void* stream) {
+    HMX_ENTER();
+    if (B == 0) return HMX_OK;
+    if (!xc || !xz || !dbc || !Wdt || !bdt || !A_log || !D || !yg || L <= 0 || !scan_shape_ok(C, ED, H)) return HMX_EINVAL;
+    ScanParams p{xc, xz, dbc, Wdt, bdt, A_log, D, (int)B, (int)L, (int)C, (int)ED, (int)H, yg, hs};
+    hipLaunchKernelGGL(scan_fwd_kernel, dim3((unsigned)B, (unsigned)hmx_ceil_div(C, 256)), dim3(256),
+                       (size_t)kScanChunk * H * kP * 4, (hipStream_t)stream, p);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int64_t hmx_scan_groups_per_head(int64_t ED) { return ED >= 64 ? ED / 64 : 1; }
+
+extern "C" int hmx_scan_bwd(const float* xc, const float* xz, const float* dbc, const float* Wdt, const float* bdt,
+                            const float* A_log, const float* D, const float* hs, const float* dyg, int64_t B, int64_t L,
+                            int64_t C, int64_t ED, int64_t H, float* dxc, float* dxz, float* ddbc_part,
+                            float* par_part, void* stream) {
+    HMX_ENTER();
+    if (B == 0) return HMX_OK;
+    if (!xc || !xz || !dbc || !Wdt || !bdt || !A_log || !D || !hs || !dyg || !dxc || !dxz || !ddbc_part || !par_part ||
+        L <= 0 || !scan_shape_ok(C, ED, H))
+        return HMX_EINVAL;
+    ScanBwdParams q{};
+    q.f = ScanParams{xc, xz, dbc, Wdt, bdt, A_log, D, (int)B, (int)L, (int)C, (int)ED, (int)H, nullptr,
+                     const_cast<float*>(hs)};
+    q.dyg = dyg;
+    q.dxc = dxc;
+    q.dxz = dxz;
+    q.ddbc_part = ddbc_part;
+    q.par_part = par_part;
+    q.GPH = (int)hmx_scan_groups_per_head(ED);
+    const dim3 grid((unsigned)B, (unsigned)hmx_ceil_div(C, 256));
+    const size_t lds = (size_t)kScanChunk * H * kP * 4;
+    if (ED >= 64) hipLaunchKernelGGL(scan_bwd_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL(scan_bwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, q);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_sum_groups_f32(const float* part, int64_t rows, int64_t groups, int64_t width, float* out,
+                                  void* stream) {
+    HMX_ENTER();
+    if (rows == 0) return HMX_OK;
+    if (!part || !out || groups <= 0 || width <= 0) return HMX_EINVAL;
+    hipLaunchKernelGGL(sum_groups_kernel, dim3(grid_for(rows * width, 256)), dim3(256), 0, (hipStream_t)stream, part, rows,
+                       (int)groups, (int)width, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}

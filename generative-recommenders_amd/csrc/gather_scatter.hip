@@ -197,6 +197,7 @@ size_t rocprim_sort_temp_bytes(int64_t n, int bits) {
 
 extern "C" int hmx_gather_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n,
                                    float* out, void* stream) {
+    HMX_ENTER();
     if (n < 0 || d <= 0 || n_rows <= 0) return HMX_EINVAL;
     if (n > 0 && (!table || !ids || !out)) return HMX_EINVAL;
     return launch_gather<false>(table, n_rows, nullptr, 0, d, ids, nullptr, n, out, (hipStream_t)stream);
@@ -205,6 +206,7 @@ extern "C" int hmx_gather_rows_f32(const float* table, int64_t n_rows, int64_t d
 extern "C" int hmx_gather_routed_f32(const float* item_table, int64_t item_rows, const float* user_table,
                                      int64_t user_rows, int64_t d, const int64_t* ids, const int64_t* token_type,
                                      int64_t n, float* out, void* stream) {
+    HMX_ENTER();
     if (n < 0 || d <= 0 || item_rows <= 0 || user_rows <= 0) return HMX_EINVAL;
     if (n > 0 && (!item_table || !user_table || !ids || !token_type || !out)) return HMX_EINVAL;
     return launch_gather<true>(item_table, item_rows, user_table, user_rows, d, ids, token_type, n, out,
@@ -220,6 +222,7 @@ extern "C" size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows
 extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
                                         int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
                                         int64_t padding_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    HMX_ENTER();
     if (n < 0 || d <= 0 || n_rows <= 0 || n >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 31)) return HMX_EINVAL;
     if (n == 0) return HMX_OK;
     if (!grad_rows || !ids || !grad_table || !workspace) return HMX_EINVAL;

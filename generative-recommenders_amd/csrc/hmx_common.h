@@ -7,13 +7,17 @@
 
 #define HMX_WAVE 64
 
+// The HIP "last error" is sticky per thread and may hold a benign error left by other code in the
+// process (an event query, a probing call): clear it on entry so that HMX_CHECK_LAUNCH reports only ours.
+#define HMX_ENTER() (void)hipGetLastError()
+
 #define HMX_CHECK_LAUNCH()                            \
     do {                                              \
         hipError_t e_ = hipGetLastError();            \
         if (e_ != hipSuccess) return HMX_ELAUNCH;     \
     } while (0)
 
-static inline int64_t hmx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t hmx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t hmx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Carves consecutive 256-byte aligned regions out of a caller-provided workspace.

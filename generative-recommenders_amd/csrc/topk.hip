@@ -22,6 +22,7 @@
 #include <cmath>
 
 #include "hmx_common.h"
+#include "profile.h"
 
 namespace {
 
@@ -593,14 +594,17 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
         p.meta_cnt = meta_cnt;
         p.meta_thr = meta_thr;
         const bool excl = exclude != nullptr && n_excl > 0;
+        void* span = nullptr;
         if (bf16) {
             const int64_t rows_pad = (int64_t)n_qtiles * qpw;
             hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)hmx_ceil_div(rows_pad * 16, 256)), dim3(256), 0, s,
                                queries + q0 * d, nq, (int)d, rows_pad, pl.dpad, q_bf16, (unsigned*)nullptr);
+            span = hmx_profile_begin("topk_coarse_bf16", s);
             if (pl.NB == 4) launch_bf16_ks<4>(p, waves, pl.KS, pl.KP, excl, s);
             else if (pl.NB == 2) launch_bf16_ks<2>(p, waves, pl.KS, pl.KP, excl, s);
             else launch_bf16_ks<1>(p, waves, pl.KS, pl.KP, excl, s);
         } else {
+            span = hmx_profile_begin("topk_coarse_f32", s);
             if (pl.KP == 32) {
                 if (excl) hipLaunchKernelGGL((coarse_f32_kernel<32, true>), dim3(waves), dim3(64), 0, s, p);
                 else hipLaunchKernelGGL((coarse_f32_kernel<32, false>), dim3(waves), dim3(64), 0, s, p);
@@ -609,6 +613,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
                 else hipLaunchKernelGGL((coarse_f32_kernel<64, false>), dim3(waves), dim3(64), 0, s, p);
             }
         }
+        hmx_profile_end(span, s);
         HMX_CHECK_LAUNCH();
         RescoreParams r{};
         r.q_f32 = queries + q0 * d;
@@ -638,6 +643,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
 
 extern "C" int hmx_table_prepare_bf16(const float* table, int64_t n_rows, int64_t d, uint16_t* table_bf16,
                                       float* max_row_norm, void* stream) {
+    HMX_ENTER();
     if (!table || !table_bf16 || !max_row_norm || n_rows <= 0 || d <= 0 || d > 128) return HMX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(max_row_norm, 0, sizeof(float), s) != hipSuccess) return HMX_ELAUNCH;
@@ -659,6 +665,7 @@ extern "C" int hmx_score_topk_f32(const float* queries, int64_t n_q, const float
                                   int64_t k, const int64_t* exclude, int64_t n_excl, int64_t id_offset,
                                   int64_t* out_ids, float* out_scores, void* workspace, size_t workspace_bytes,
                                   void* stream) {
+    HMX_ENTER();
     return run_topk(false, queries, n_q, table, nullptr, nullptr, n_rows, d, k, exclude, n_excl, id_offset, out_ids,
                     out_scores, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -668,12 +675,14 @@ extern "C" int hmx_score_topk_bf16(const float* queries, int64_t n_q, const floa
                                    const int64_t* exclude, int64_t n_excl, int64_t id_offset, int64_t* out_ids,
                                    float* out_scores, int32_t* uncertain, void* workspace, size_t workspace_bytes,
                                    void* stream) {
+    HMX_ENTER();
     return run_topk(true, queries, n_q, table, table_bf16, max_row_norm, n_rows, d, k, exclude, n_excl, id_offset,
                     out_ids, out_scores, uncertain, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_shards, int64_t n_q,
                               int64_t k, int64_t* out_ids, float* out_scores, void* stream) {
+    HMX_ENTER();
     if (n_q == 0) return HMX_OK;
     if (!cand_ids || !cand_scores || !out_ids || !out_scores || n_shards <= 0 || k <= 0 || n_shards * k > 1024)
         return HMX_EINVAL;

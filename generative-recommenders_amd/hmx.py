@@ -25,6 +25,8 @@ PROTOTYPES = {
     "hmx_score_topk_f32": (c_int, [P, I64, P, I64, I64, I64, P, I64, I64, P, P, P, c_size_t, P]),
     "hmx_score_topk_bf16": (c_int, [P, I64, P, P, P, I64, I64, I64, P, I64, I64, P, P, P, P, c_size_t, P]),
     "hmx_topk_merge": (c_int, [P, P, I64, I64, I64, P, P, P]),
+    "hmx_profile_enable": (c_int, [c_int]),
+    "hmx_profile_collect": (c_int, [c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }
 
 _lib = None
@@ -64,3 +66,14 @@ def ptr(t):
 def current_stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def profile_enable(on=True):
+    check(lib().hmx_profile_enable(1 if on else 0), "hmx_profile_enable")
+
+
+def profile_collect(tag):
+    """-> (total milliseconds, launches) of the spans recorded under `tag` since the last collect."""
+    ms, n = ctypes.c_double(0.0), c_int64(0)
+    check(lib().hmx_profile_collect(tag.encode(), ctypes.byref(ms), ctypes.byref(n)), "hmx_profile_collect")
+    return ms.value, n.value

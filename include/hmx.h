@@ -108,6 +108,15 @@ int hmx_score_topk_bf16(const float* queries, int64_t n_q, const float* table, c
 int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_shards, int64_t n_q, int64_t k,
                    int64_t* out_ids, float* out_scores, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Benchmark support (no counterpart in the reference).  When enabled, entry points bracket
+ * their dominant kernel with HIP events on the caller's stream; hmx_profile_collect blocks
+ * until the events of spans tagged `tag` have completed, returns their summed duration and
+ * count, and forgets them.  Tags: "topk_coarse_bf16", "topk_coarse_f32".
+ * ------------------------------------------------------------------------------- */
+int hmx_profile_enable(int on);
+int hmx_profile_collect(const char* tag, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

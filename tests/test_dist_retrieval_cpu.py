@@ -1,0 +1,56 @@
+"""world_size-2 gloo test of the sharded-retrieval exchange logic (no GPU): the local scorer and the merge are
+the oracle's, injected into the same ShardedRetriever the GPU path uses."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from generative_recommenders_amd.retrieval import ShardedRetriever, shard_bounds
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    from oracle import c_oracle as C
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((2501, 16)).astype(np.float32)
+    q = torch.from_numpy(rng.standard_normal((70, 16)).astype(np.float32))
+    lo, hi = shard_bounds(table.shape[0], world, rank)
+    shard = table[lo:hi]
+
+    def local(queries, k):
+        ids, sc = C.score_topk(queries.numpy(), shard, k, id_offset=lo)
+        return torch.from_numpy(ids), torch.from_numpy(sc)
+
+    def merge(ci, cs):
+        ids, sc = C.topk_merge(ci.numpy(), cs.numpy())
+        return torch.from_numpy(ids), torch.from_numpy(sc)
+
+    r = ShardedRetriever(None, id_offset=lo, local_topk=local, merge=merge, chunk=32)
+    ids, sc = r.search(q, 10)
+    want_ids, want_sc = C.score_topk(q.numpy(), table, 10)
+    ok = np.array_equal(ids.numpy(), want_ids) and np.array_equal(sc.numpy(), want_sc)
+    with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
+        f.write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_retrieval_equals_unsharded(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(2)] == ["1", "1"]
+
+
+def test_shard_bounds_cover_and_do_not_overlap():
+    for n, w in ((4_000_001, 8), (10, 3), (5, 8), (1, 2)):
+        spans = [shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
