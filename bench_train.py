@@ -1,0 +1,130 @@
+"""Train-step workload of bench.py: hydra3 forward + backward (+ clip + AdamW) on synthetic ids,
+batch 1024 x seq 100, d 64, 1 M users, 4 M items (BASELINE.json configs[1]).
+
+The step reproduces the call sequence of main.py:684-713 with the drop-in modules: zero_grad, Hydra.forward
+(encoder, miner top-50 over the whole item table, InfoNCE with the 153-way hard-negative gather), backward
+(scatter-add into dense table gradients), clip_grad_norm_(1.0), AdamW(lr 1e-3, betas (0.9, 0.98), wd 0.1).
+Differences from the reference's loop, stated here: compute is fp32 with bf16 MFMA inside the projection
+kernels instead of fp16 autocast + GradScaler; the loss is evaluated in query chunks of `loss_q_chunk`
+(default 16384; the reference uses 256) -- same estimator, fewer launches.
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def _sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def cpu_baseline_train(args, seconds_cap=40.0):
+    """The CPU oracle (fixture-verified restatement of the reference) on this box's host cores: one forward +
+    backward of the same model (1 M users, 4 M items, d 64, L 100) on a bounded batch of 32 sequences."""
+    from oracle import hydra_oracle as O
+    from generative_recommenders_amd import synth
+    threads = torch.get_num_threads()
+    B = 32
+    model = O.build_model(args.users, args.items, d=args.dim, L=args.seq_len, dropout=0.2, seed=1).train()
+    bt = synth.train_batch(B, args.seq_len, args.users, args.items, "cpu", seed=2)
+    feat = [[] for _ in range(B)]
+    t0 = time.time()
+    loss = model(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"],
+                 bt["act"], bt["dwell"])
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": B / dt, "unit": "user seqs/s", "cores": threads, "kind": "port",
+            "sample": f"one fwd+bwd of {B} sequences x {args.seq_len}, same model and tables, PyTorch CPU oracle on "
+                      f"{threads} threads ({dt:.1f} s)"}
+
+
+def run_train(args, world, rank, with_cpu_baseline=True):
+    from generative_recommenders_amd import hmx, synth
+    from generative_recommenders_amd import hydra as H
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, L, d = args.batch, args.seq_len, args.dim
+    model = H.build_model(args.users, args.items, d=d, L=L, dropout=0.2, device=dev, seed=1234, loss_q_chunk=16384)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1)
+    bt = synth.train_batch(B, L, args.users, args.items, dev, seed=99 + rank)
+    feat = [[] for _ in range(B)]
+    sync_grads = None
+    if world > 1:
+        from generative_recommenders_amd.parallel import GradientSync
+        sync_grads = GradientSync(model)
+
+    def step(timers=None):
+        opt.zero_grad(set_to_none=True)
+        loss = model(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"],
+                     bt["act"], bt["dwell"])
+        loss.backward()
+        if timers is not None:
+            timers.append(torch.cuda.Event(enable_timing=True))
+            timers[-1].record()
+        if sync_grads is not None:
+            sync_grads()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    hmx.profile_enable(True)
+    for tag in ("gather_rows", "scatter_segment_sum", "topk_coarse_bf16"):
+        hmx.profile_collect(tag)
+    _sync(world)
+    starts, mids = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        starts.append(torch.cuda.Event(enable_timing=True))
+        starts[-1].record()
+        loss = step(mids)
+    _sync(world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    spans = {tag: hmx.profile_collect(tag) for tag in ("gather_rows", "scatter_segment_sum", "topk_coarse_bf16")}
+    hmx.profile_enable(False)
+    fwd_bwd_ms = sum(s.elapsed_time(m) for s, m in zip(starts, mids)) / args.steps
+    step_s = elapsed / args.steps
+
+    # algorithmic bytes of the row gathers of one step: routed seq gather + pos + 4 small tables (B*L ids each, 3 of
+    # them on the big tables) + hard negatives (valid positions x 153); 8 B index + d*4 read + d*4 write per id
+    M = int((bt["next_tok"] == 1).sum().item())
+    n_ids = 6 * B * L + M * 153
+    g_ms, g_n = spans["gather_rows"]
+    gather_gbs = n_ids * (8 + 2 * d * 4) * args.steps / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+    c_ms, c_n = spans["topk_coarse_bf16"]
+    miner_tf = 2.0 * B * (args.items + 1) * d * args.steps / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
+    s_ms, s_n = spans["scatter_segment_sum"]
+    out = {
+        "metric": "user seqs/s hydra3 fwd+bwd", "value": B * world / step_s, "unit": "user seqs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": step_s * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "hydra3 train step fwd+bwd with embedding scatter-add, batch 1024 x seq 100 (configs[1])",
+                   "batch_per_gpu": B, "seq_len": L, "d": d, "users": args.users, "items": args.items,
+                   "includes": "zero_grad, forward (encoder + miner top-50 + InfoNCE), backward, clip_grad_norm, AdamW",
+                   "loss_q_chunk": 16384, "parallelism": f"dp{world}" if world > 1 else "single GPU"},
+        "fwd_bwd_ms": fwd_bwd_ms, "fwd_bwd_seqs_per_s": B * world / (fwd_bwd_ms * 1e-3), "loss": float(loss.item()),
+        "roofline": {"bound": "hbm", "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gather_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "gather_rows_kernel",
+                     "launches": g_n, "avg_launch_ms": g_ms / max(g_n, 1),
+                     "algorithmic_bytes_per_step": n_ids * (8 + 2 * d * 4)},
+        "other_kernels": {
+            "coarse_bf16_kernel (miner, mfma)": {"achieved_tflops": miner_tf, "frac_of_2500": miner_tf / 2500.0,
+                                                 "ms_per_step": c_ms / args.steps},
+            "segment_sum_kernel (scatter-add, hbm)": {"ms_per_step": s_ms / args.steps, "launches": s_n}},
+    }
+    if with_cpu_baseline and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del model, opt
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline_train(args)
+    return out

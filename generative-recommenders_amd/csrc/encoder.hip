@@ -137,18 +137,24 @@ struct LinearParams {
     int accumulate;            // Y = Y_old + result
 };
 
-template <int KS>
+// SPLIT = false: one bf16 MFMA per product (inputs rounded to bf16, relative error ~2^-9 per operand).
+// SPLIT = true : every operand is split x = hi + lo (two bf16 numbers, 16 significant bits together) and the product
+//                is accumulated as hi*hi + lo*hi + hi*lo on the same MFMA: fp32-class accuracy at three MFMAs.
+template <int KS, bool SPLIT>
 __global__ __launch_bounds__(256) void linear_kernel(LinearParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KP = KS * 16 + 8;  // bf16 elements per LDS row (+8 keeps ds_read_b128 conflict-free)
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* wl_lo = wl + (size_t)p.n_chunk * KP;
     const int n_base = blockIdx.y * p.n_chunk;
     const int nc = min(p.n_chunk, p.N - n_base);
     const int npad = (nc + 31) / 32 * 32;
     for (int idx = threadIdx.x; idx < npad * KS * 16; idx += 256) {
         const int n = idx / (KS * 16), k = idx % (KS * 16);
         const float v = (n < nc && k < p.K) ? p.W[(int64_t)(n_base + n) * p.w_rs + (int64_t)k * p.w_cs] : 0.f;
-        wl[n * KP + k] = hmx_f32_to_bf16(v);
+        const uint16_t hi = hmx_f32_to_bf16(v);
+        wl[n * KP + k] = hi;
+        if (SPLIT) wl_lo[n * KP + k] = hmx_f32_to_bf16(v - hmx_bf16_to_f32(hi));
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearParams p) {
         const bool ok = t < p.T;
         const float im = (ok && p.in_rowmask) ? p.in_rowmask[t] : 1.f;
         const float* xr = p.X + (ok ? t : 0) * p.ldx;
-        short8 a[KS];
+        short8 a[KS], a_lo[SPLIT ? KS : 1];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k0 = 16 * ks + 8 * h;
@@ -173,7 +179,12 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearParams p) {
                 for (int e = 0; e < 8; ++e) v[e] = (ok && k0 + e < p.K) ? xr[k0 + e] : 0.f;
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[ks][e] = (short)hmx_f32_to_bf16(v[e] * im);
+            for (int e = 0; e < 8; ++e) {
+                const float xv = v[e] * im;
+                const uint16_t hb = hmx_f32_to_bf16(xv);
+                a[ks][e] = (short)hb;
+                if (SPLIT) a_lo[ks][e] = (short)hmx_f32_to_bf16(xv - hmx_bf16_to_f32(hb));
+            }
         }
         for (int nt = 0; nt < npad / 32; ++nt) {
             f32x16 acc;
@@ -181,7 +192,13 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearParams p) {
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const short8 b = *reinterpret_cast<const short8*>(wl + (nt * 32 + i) * KP + 16 * ks + 8 * h);
+                const int off = (nt * 32 + i) * KP + 16 * ks + 8 * h;
+                const short8 b = *reinterpret_cast<const short8*>(wl + off);
+                if (SPLIT) {
+                    const short8 b_lo = *reinterpret_cast<const short8*>(wl_lo + off);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b_lo, acc, 0, 0, 0);
+                }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b, acc, 0, 0, 0);
             }
             const int n = n_base + nt * 32 + i;
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
     const int c = blockIdx.y * 256 + threadIdx.x;
     const bool live = c < p.C;
     const int cc = live ? c : 0;
-    const int hh = cc / p.ED, ce = cc % p.ED;
+    const int hh = cc / p.ED;
     const int64_t seq = blockIdx.x;
     const int HP = p.H * kP;
     float A[kN], Wd[kR], h[kN];
@@ -453,7 +470,6 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
         for (int s = 0; s < steps; ++s) {
             const int64_t row = seq * p.L + tc0 + s;
             const float x = p.xc[row * p.C + c];
-            const float z = p.xz[row * p.C + c];
             const float* r = rows + s * HP + hh * kP;
             float dpre = 0.f;
 #pragma unroll
@@ -471,7 +487,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
             }
-            p.yg[row * p.C + c] = (y + Dv * x) * silu_(z);
+            p.yg[row * p.C + c] = (y + Dv * x) * (p.xz ? silu_(p.xz[row * p.C + c]) : 1.f);
         }
     }
 }
@@ -550,7 +566,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(ScanBwdParams q) {
         for (int s = steps - 1; s >= 0; --s) {
             const int64_t row = seq * p.L + tc0 + s;
             const float x = p.xc[row * p.C + c];
-            const float z = p.xz[row * p.C + c];
+            const float z = p.xz ? p.xz[row * p.C + c] : 0.f;
             const float gy = q.dyg[row * p.C + c];
             const float* r = rows + s * HP + hh * kP;
             float hcur[kN];
@@ -571,9 +587,8 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(ScanBwdParams q) {
 #pragma unroll
             for (int n = 0; n < kN; ++n) y += hcur[n] * r[kR + kN + n];
             const float ypre = y + Dv * x;
-            const float sz = silu_(z);
-            const float dy = gy * sz;
-            q.dxz[row * p.C + c] = gy * ypre * silu_grad_(z);
+            const float dy = p.xz ? gy * silu_(z) : gy;
+            if (p.xz) q.dxz[row * p.C + c] = gy * ypre * silu_grad_(z);
             dD += dy * x;
             float dx = Dv * dy, ddelta = 0.f;
             float vB[kN], vC[kN];
@@ -680,6 +695,24 @@ extern "C" int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_
     return HMX_OK;
 }
 
+static int g_linear_split = 1;   // 1: split-bf16 (three MFMAs per product, fp32-class accuracy); 0: single bf16 MFMA
+
+extern "C" int hmx_set_linear_precision(int split_bf16) {
+    g_linear_split = split_bf16 != 0;
+    return HMX_OK;
+}
+
+template <bool SPLIT>
+static void launch_linear(int ks, dim3 grid, size_t lds, hipStream_t s, const LinearParams& p) {
+    switch (ks) {
+        case 1: hipLaunchKernelGGL((linear_kernel<1, SPLIT>), grid, dim3(256), lds, s, p); break;
+        case 2: hipLaunchKernelGGL((linear_kernel<2, SPLIT>), grid, dim3(256), lds, s, p); break;
+        case 4: hipLaunchKernelGGL((linear_kernel<4, SPLIT>), grid, dim3(256), lds, s, p); break;
+        case 8: hipLaunchKernelGGL((linear_kernel<8, SPLIT>), grid, dim3(256), lds, s, p); break;
+        default: hipLaunchKernelGGL((linear_kernel<16, SPLIT>), grid, dim3(256), lds, s, p); break;
+    }
+}
+
 extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, int64_t w_cs,
                               const float* bias, int64_t T, int64_t N, int64_t K, float* Y, int64_t ldy,
                               const float* R1, int64_t ldr1, float c1, const float* R2, int64_t ldr2, float c2,
@@ -691,20 +724,15 @@ extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64
                    in_rowmask, out_rowmask, accumulate};
     const int ks = ks_for((int)K);
     const int kp = ks * 16 + 8;
-    int n_chunk = std::min<int>(256, (60 * 1024 / (kp * 2)) / 32 * 32);
+    const int copies = g_linear_split ? 2 : 1;
+    int n_chunk = std::min<int>(256, (60 * 1024 / (kp * 2 * copies)) / 32 * 32);
     n_chunk = std::min<int>(n_chunk, (int)((N + 31) / 32 * 32));
     p.n_chunk = n_chunk;
-    const size_t lds = (size_t)n_chunk * kp * 2;
+    const size_t lds = (size_t)n_chunk * kp * 2 * copies;
     const dim3 grid((unsigned)std::min<int64_t>(hmx_ceil_div(hmx_ceil_div(T, 32), 4), 1024),
                     (unsigned)hmx_ceil_div(N, n_chunk));
-    hipStream_t s = (hipStream_t)stream;
-    switch (ks) {
-        case 1: hipLaunchKernelGGL(linear_kernel<1>, grid, dim3(256), lds, s, p); break;
-        case 2: hipLaunchKernelGGL(linear_kernel<2>, grid, dim3(256), lds, s, p); break;
-        case 4: hipLaunchKernelGGL(linear_kernel<4>, grid, dim3(256), lds, s, p); break;
-        case 8: hipLaunchKernelGGL(linear_kernel<8>, grid, dim3(256), lds, s, p); break;
-        default: hipLaunchKernelGGL(linear_kernel<16>, grid, dim3(256), lds, s, p); break;
-    }
+    if (g_linear_split) launch_linear<true>(ks, grid, lds, (hipStream_t)stream, p);
+    else launch_linear<false>(ks, grid, lds, (hipStream_t)stream, p);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -835,7 +863,7 @@ extern "C" int hmx_scan_fwd(const float* xc, const float* xz, const float* dbc, 
                             float* yg, float* hs, void* stream) {
     HMX_ENTER();
     if (B == 0) return HMX_OK;
-    if (!xc || !xz || !dbc || !Wdt || !bdt || !A_log || !D || !yg || L <= 0 || !scan_shape_ok(C, ED, H)) return HMX_EINVAL;
+    if (!xc || !dbc || !Wdt || !bdt || !A_log || !D || !yg || L <= 0 || !scan_shape_ok(C, ED, H)) return HMX_EINVAL;
     ScanParams p{xc, xz, dbc, Wdt, bdt, A_log, D, (int)B, (int)L, (int)C, (int)ED, (int)H, yg, hs};
     hipLaunchKernelGGL(scan_fwd_kernel, dim3((unsigned)B, (unsigned)hmx_ceil_div(C, 256)), dim3(256),
                        (size_t)kScanChunk * H * kP * 4, (hipStream_t)stream, p);
@@ -851,7 +879,7 @@ extern "C" int hmx_scan_bwd(const float* xc, const float* xz, const float* dbc, 
                             float* par_part, void* stream) {
     HMX_ENTER();
     if (B == 0) return HMX_OK;
-    if (!xc || !xz || !dbc || !Wdt || !bdt || !A_log || !D || !hs || !dyg || !dxc || !dxz || !ddbc_part || !par_part ||
+    if (!xc || !dbc || !Wdt || !bdt || !A_log || !D || !hs || !dyg || !dxc || (xz && !dxz) || !ddbc_part || !par_part ||
         L <= 0 || !scan_shape_ok(C, ED, H))
         return HMX_EINVAL;
     ScanBwdParams q{};

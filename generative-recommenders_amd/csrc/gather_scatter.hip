@@ -10,6 +10,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "hmx_common.h"
+#include "profile.h"
 
 namespace {
 
@@ -94,12 +95,14 @@ int launch_gather(const float* t0, int64_t r0, const float* t1, int64_t r1, int6
     const int l2 = lpr_log2_for(cpr);
     const int64_t rows_per_block = (kBlock >> l2) * kUnroll;
     const int grid = (int)std::min<int64_t>(hmx_ceil_div(n, rows_per_block), kMaxGrid);
+    void* span = hmx_profile_begin("gather_rows", s);
     if (vec)
         hipLaunchKernelGGL((gather_rows_kernel<4, ROUTED>), dim3(grid), dim3(kBlock), 0, s, t0, r0, t1, r1, (int)cpr,
                            l2, ids, tt, n, out);
     else
         hipLaunchKernelGGL((gather_rows_kernel<1, ROUTED>), dim3(grid), dim3(kBlock), 0, s, t0, r0, t1, r1, (int)cpr,
                            l2, ids, tt, n, out);
+    hmx_profile_end(span, s);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -252,12 +255,14 @@ extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* i
     const int l2 = lpr_log2_for(cpr);
     const int64_t groups = hmx_ceil_div(n, kChunk);
     const int grid3 = (int)std::min<int64_t>(hmx_ceil_div(groups, kBlock >> l2), (int64_t)kMaxGrid * 4);
+    void* span = hmx_profile_begin("scatter_segment_sum", s);
     if (vec)
         hipLaunchKernelGGL(segment_sum_kernel<4>, dim3(grid3), dim3(kBlock), 0, s, grad_rows, skeys, svals, n, (int)cpr,
                            l2, sentinel, grad_table);
     else
         hipLaunchKernelGGL(segment_sum_kernel<1>, dim3(grid3), dim3(kBlock), 0, s, grad_rows, skeys, svals, n, (int)cpr,
                            l2, sentinel, grad_table);
+    hmx_profile_end(span, s);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }

@@ -173,8 +173,10 @@ __device__ __forceinline__ void finish_group(float& thr, int& cnt, uint2* group_
     meta_thr[threadIdx.x] = thr;
 }
 
+// launch bound of 2 waves per SIMD caps the kernel at 256 registers, which also makes the compiler keep the
+// MFMA accumulators in VGPRs (the filter reads them every tile; AGPR accumulators cost a v_accvgpr_read each).
 template <int NB, int KS, int KP, bool EXCL>
-__global__ __launch_bounds__(64) void coarse_bf16_kernel(CoarseParams p) {
+__global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
     constexpr int CAP = 2 * KP;
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     int qtile, split;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64) void coarse_bf16_kernel(CoarseParams p) {
 // fp32 MFMA: D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) per instruction, k0 on lanes 0-31, k1 on 32-63,
 // so stepping k by 2 reproduces the k-ordered fma chain bit for bit.
 template <int KP, bool EXCL>
-__global__ __launch_bounds__(64) void coarse_f32_kernel(CoarseParams p) {
+__global__ __launch_bounds__(64, 2) void coarse_f32_kernel(CoarseParams p) {
     constexpr int CAP = 2 * KP;
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     int qtile, split;
@@ -504,6 +506,7 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
     pl.KS = pl.dpad / 16;
     pl.NB = 1;
     if (bf16) pl.NB = n_q >= 16384 ? 4 : (n_q >= 4096 ? 2 : 1);
+    if (bf16 && pl.KS == 8 && pl.NB == 4) pl.NB = 2;   // d = 128: four query groups would not fit 256 registers
     const int64_t qpw = 32 * pl.NB;
     pl.chunk = std::min<int64_t>(hmx_ceil_div(n_q, qpw) * qpw, 2048 * qpw);
     pl.n_qtiles = (int)(pl.chunk / qpw);

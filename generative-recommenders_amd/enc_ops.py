@@ -1,0 +1,386 @@
+"""torch.autograd wrappers for the encoder kernels of libhmx.so.
+
+All tensors are CUDA fp32; token-major (T, features).  No CPU fallback.
+"""
+import math
+
+import torch
+
+from . import hmx
+from .ops import _f32c, _i64c, _need_cuda, workspace
+
+N_STATE = 16
+DT_RANK = 16
+P_DBC = DT_RANK + 2 * N_STATE
+
+
+def _s():
+    return hmx.current_stream()
+
+
+def _L():
+    return hmx.lib()
+
+
+def _empty(*shape, like):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+def colsum(P):
+    """(rows, cols) -> (cols): deterministic column sums."""
+    P = _f32c(P)
+    rows, cols = P.shape
+    out = _empty(cols, like=P)
+    hmx.check(_L().hmx_colsum_f32(hmx.ptr(P), rows, cols, cols, hmx.ptr(out), _s()), "hmx_colsum_f32")
+    return out
+
+
+def combine(xs, coefs, rowmask=None):
+    """(sum_i coefs[i] * xs[i]) * rowmask[:, None] for up to four (T, d) tensors."""
+    xs = [_f32c(x) for x in xs]
+    T, d = xs[0].shape
+    out = _empty(T, d, like=xs[0])
+    p = [hmx.ptr(x) for x in xs] + [None] * (4 - len(xs))
+    c = list(coefs) + [0.0] * (4 - len(xs))
+    hmx.check(_L().hmx_combine_f32(p[0], p[1], p[2], p[3], c[0], c[1], c[2], c[3], hmx.ptr(rowmask), T, d,
+                                   hmx.ptr(out), _s()), "hmx_combine_f32")
+    return out
+
+
+class _Combine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rowmask, c0, c1, c2, c3, *xs):
+        ctx.coefs = (c0, c1, c2, c3)[:len(xs)]
+        ctx.save_for_backward(rowmask) if rowmask is not None else None
+        ctx.has_mask = rowmask is not None
+        return combine(xs, ctx.coefs, rowmask)
+
+    @staticmethod
+    def backward(ctx, g):
+        rm = ctx.saved_tensors[0] if ctx.has_mask else None
+        g = _f32c(g)
+        grads = []
+        for i, c in enumerate(ctx.coefs):
+            if not ctx.needs_input_grad[5 + i]:
+                grads.append(None)
+            elif rm is None and c == 1.0:
+                grads.append(g)
+            else:
+                grads.append(combine([g], [c], rm))
+        return (None, None, None, None, None, *grads)
+
+
+def combine_ad(xs, coefs, rowmask=None):
+    c = list(coefs) + [0.0] * (4 - len(xs))
+    return _Combine.apply(rowmask, c[0], c[1], c[2], c[3], *xs)
+
+
+# ------------------------------------------------------------------------------- RMSNorm
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, eps):
+        _need_cuda(x, scale)
+        x, scale = _f32c(x), _f32c(scale)
+        T, d = x.shape
+        y, rstd = _empty(T, d, like=x), _empty(T, like=x)
+        hmx.check(_L().hmx_rmsnorm_fwd(hmx.ptr(x), hmx.ptr(scale), T, d, eps, hmx.ptr(y), hmx.ptr(rstd), _s()),
+                  "hmx_rmsnorm_fwd")
+        ctx.save_for_backward(x, scale, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, rstd = ctx.saved_tensors
+        dy = _f32c(dy)
+        T, d = x.shape
+        nb = _L().hmx_rmsnorm_bwd_blocks(T)
+        dx, part = _empty(T, d, like=x), _empty(nb, d, like=x)
+        hmx.check(_L().hmx_rmsnorm_bwd(hmx.ptr(x), hmx.ptr(scale), hmx.ptr(rstd), hmx.ptr(dy), T, d, hmx.ptr(dx),
+                                       hmx.ptr(part), _s()), "hmx_rmsnorm_bwd")
+        return dx, colsum(part), None
+
+
+def rmsnorm(x, scale, eps=1e-6):
+    return _RMSNorm.apply(x, scale, eps)
+
+
+# ------------------------------------------------------------------------------- linear
+def _linear_raw(x_ptr, ldx, w_ptr, w_rs, w_cs, bias, T, N, K, y_ptr, ldy, r1=None, c1=0.0, r2=None, c2=0.0,
+                in_mask=None, out_mask=None, accumulate=False):
+    hmx.check(_L().hmx_linear_f32(x_ptr, ldx, w_ptr, w_rs, w_cs, hmx.ptr(bias), T, N, K, y_ptr, ldy,
+                                  hmx.ptr(r1), N if r1 is not None else 0, c1, hmx.ptr(r2), N if r2 is not None else 0,
+                                  c2, hmx.ptr(in_mask), hmx.ptr(out_mask), 1 if accumulate else 0, _s()),
+              "hmx_linear_f32")
+
+
+def _wgrad_raw(dy_ptr, ldy, x_ptr, ldx, in_mask, T, N, K, dw_ptr, ldw, db, device):
+    ws = workspace(_L().hmx_linear_wgrad_workspace_bytes(T, N, K), device)
+    hmx.check(_L().hmx_linear_wgrad_f32(dy_ptr, ldy, x_ptr, ldx, hmx.ptr(in_mask), T, N, K, dw_ptr, ldw, hmx.ptr(db),
+                                        hmx.ptr(ws), ws.numel(), _s()), "hmx_linear_wgrad_f32")
+
+
+class _Linear(torch.autograd.Function):
+    """y = ((x * in_mask) W[:, :K]^T + b + c1 r1 + c2 r2) * out_mask   (at most one of the masks)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_mask, out_mask, r1, c1, r2, c2):
+        _need_cuda(x, weight)
+        assert in_mask is None or out_mask is None
+        x, w = _f32c(x), _f32c(weight)
+        T, K = x.shape
+        N, ldw = w.shape
+        assert ldw >= K
+        r1 = _f32c(r1) if r1 is not None else None
+        r2 = _f32c(r2) if r2 is not None else None
+        y = _empty(T, N, like=x)
+        _linear_raw(hmx.ptr(x), K, hmx.ptr(w), ldw, 1, bias, T, N, K, hmx.ptr(y), N, r1, c1, r2, c2, in_mask, out_mask)
+        ctx.save_for_backward(x, w, in_mask, out_mask)
+        ctx.c = (c1, c2)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, in_mask, out_mask = ctx.saved_tensors
+        T, K = x.shape
+        N, ldw = w.shape
+        g = _f32c(dy)
+        if out_mask is not None:
+            g = combine([g], [1.0], out_mask)
+        need = ctx.needs_input_grad
+        dx = dw = db = dr1 = dr2 = None
+        if need[0]:
+            dx = _empty(T, K, like=x)
+            _linear_raw(hmx.ptr(g), N, hmx.ptr(w), 1, ldw, None, T, K, N, hmx.ptr(dx), K, out_mask=in_mask)
+        if need[1]:
+            dw = torch.zeros_like(w) if ldw > K else torch.empty_like(w)
+            db = _empty(N, like=x) if (ctx.has_bias and need[2]) else None
+            _wgrad_raw(hmx.ptr(g), N, hmx.ptr(x), K, in_mask, T, N, K, hmx.ptr(dw), ldw, db, x.device)
+        if need[5]:
+            dr1 = g if ctx.c[0] == 1.0 else combine([g], [ctx.c[0]])
+        if need[7]:
+            dr2 = g if ctx.c[1] == 1.0 else combine([g], [ctx.c[1]])
+        return dx, dw, db, None, None, dr1, None, dr2, None
+
+
+def linear(x, weight, bias=None, in_mask=None, out_mask=None, r1=None, c1=0.0, r2=None, c2=0.0):
+    """nn.Linear forward on bf16 MFMA; uses the first x.shape[1] columns of `weight`."""
+    return _Linear.apply(x, weight, bias, in_mask, out_mask, r1, float(c1), r2, float(c2))
+
+
+class _HeadsLinear(torch.autograd.Function):
+    """Block-diagonal projection: y[:, h*n_out:(h+1)*n_out] = x[:, h*k_in:(h+1)*k_in] W_h^T for every head h."""
+
+    @staticmethod
+    def forward(ctx, x, *weights):
+        _need_cuda(x)
+        x = _f32c(x)
+        ws = [_f32c(w) for w in weights]
+        H = len(ws)
+        n_out, k_in = ws[0].shape
+        T = x.shape[0]
+        assert x.shape[1] == H * k_in
+        y = _empty(T, H * n_out, like=x)
+        for h, w in enumerate(ws):
+            _linear_raw(x.data_ptr() + 4 * h * k_in, H * k_in, hmx.ptr(w), k_in, 1, None, T, n_out, k_in,
+                        y.data_ptr() + 4 * h * n_out, H * n_out)
+        ctx.save_for_backward(x, *ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *ws = ctx.saved_tensors
+        g = _f32c(dy)
+        H = len(ws)
+        n_out, k_in = ws[0].shape
+        T = x.shape[0]
+        dx = _empty(T, H * k_in, like=x) if ctx.needs_input_grad[0] else None
+        dws = []
+        for h, w in enumerate(ws):
+            gp = g.data_ptr() + 4 * h * n_out
+            if dx is not None:
+                _linear_raw(gp, H * n_out, hmx.ptr(w), 1, k_in, None, T, k_in, n_out, dx.data_ptr() + 4 * h * k_in,
+                            H * k_in)
+            if ctx.needs_input_grad[1 + h]:
+                dw = torch.empty_like(w)
+                _wgrad_raw(gp, H * n_out, x.data_ptr() + 4 * h * k_in, H * k_in, None, T, n_out, k_in, hmx.ptr(dw),
+                           k_in, None, x.device)
+                dws.append(dw)
+            else:
+                dws.append(None)
+        return (dx, *dws)
+
+
+def heads_linear(x, weights):
+    return _HeadsLinear.apply(x, *weights)
+
+
+# ------------------------------------------------------------------------------- pointwise
+_ROPE_CACHE = {}
+
+
+def rope_tables(L, hd, device):
+    """cos/sin of t * 10000^(-2i/hd), t = 0..L-1 (hydra3.py:318-328), computed once on the CPU in fp32."""
+    key = (L, hd, str(device))
+    if key not in _ROPE_CACHE:
+        theta = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+        ang = torch.arange(L, dtype=torch.float32)[:, None] * theta[None, :]
+        _ROPE_CACHE[key] = (torch.cos(ang).to(device).contiguous(), torch.sin(ang).to(device).contiguous())
+    return _ROPE_CACHE[key]
+
+
+class _SiluRope(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, L, hd):
+        _need_cuda(x1)
+        x1 = _f32c(x1)
+        T, d = x1.shape
+        cs, sn = rope_tables(L, hd, x1.device)
+        s, y2 = _empty(T, d, like=x1), _empty(T, d, like=x1)
+        hmx.check(_L().hmx_silu_rope_fwd(hmx.ptr(x1), hmx.ptr(cs), hmx.ptr(sn), T, L, d, hd, hmx.ptr(s), hmx.ptr(y2),
+                                         _s()), "hmx_silu_rope_fwd")
+        ctx.save_for_backward(x1)
+        ctx.dims = (L, hd)
+        return s, y2
+
+    @staticmethod
+    def backward(ctx, ds, dy2):
+        (x1,) = ctx.saved_tensors
+        L, hd = ctx.dims
+        T, d = x1.shape
+        cs, sn = rope_tables(L, hd, x1.device)
+        ds = _f32c(ds) if ds is not None else torch.zeros_like(x1)
+        dy2 = _f32c(dy2) if dy2 is not None else torch.zeros_like(x1)
+        dx1 = torch.empty_like(x1)
+        hmx.check(_L().hmx_silu_rope_bwd(hmx.ptr(x1), hmx.ptr(cs), hmx.ptr(sn), hmx.ptr(ds), hmx.ptr(dy2), T, L, d, hd,
+                                         hmx.ptr(dx1), _s()), "hmx_silu_rope_bwd")
+        return dx1, None, None
+
+
+def silu_rope(x1, L, hd):
+    return _SiluRope.apply(x1, L, hd)
+
+
+class _Binary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c, mode):
+        _need_cuda(a, b)
+        a, b = _f32c(a), _f32c(b)
+        out = torch.empty_like(a)
+        hmx.check(_L().hmx_binary_fwd(hmx.ptr(a), hmx.ptr(b), a.numel(), c, mode, hmx.ptr(out), _s()), "hmx_binary_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.cm = (c, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _f32c(g)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        hmx.check(_L().hmx_binary_bwd(hmx.ptr(a), hmx.ptr(b), hmx.ptr(g), a.numel(), ctx.cm[0], ctx.cm[1], hmx.ptr(da),
+                                      hmx.ptr(db), _s()), "hmx_binary_bwd")
+        return da, db, None, None
+
+
+def mul_scale(a, b, c):
+    return _Binary.apply(a, b, float(c), 0)
+
+
+def swiglu(gate, up):
+    return _Binary.apply(gate, up, 1.0, 1)
+
+
+# ------------------------------------------------------------------------------- conv + scan
+class _ConvSilu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, L):
+        _need_cuda(x, w, b)
+        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        T, C = x.shape
+        xc = torch.empty_like(x)
+        hmx.check(_L().hmx_conv_silu_fwd(hmx.ptr(x), hmx.ptr(w), hmx.ptr(b), T, L, C, hmx.ptr(xc), _s()),
+                  "hmx_conv_silu_fwd")
+        ctx.save_for_backward(x, w, b)
+        ctx.L = L
+        return xc
+
+    @staticmethod
+    def backward(ctx, dxc):
+        x, w, b = ctx.saved_tensors
+        T, C = x.shape
+        B = T // ctx.L
+        dxc = _f32c(dxc)
+        dx, part = torch.empty_like(x), _empty(B, C * 5, like=x)
+        hmx.check(_L().hmx_conv_silu_bwd(hmx.ptr(x), hmx.ptr(w), hmx.ptr(b), hmx.ptr(dxc), B, ctx.L, C, hmx.ptr(dx),
+                                         hmx.ptr(part), _s()), "hmx_conv_silu_bwd")
+        pg = colsum(part).view(C, 5)
+        return dx, pg[:, :4].contiguous(), pg[:, 4].contiguous(), None
+
+
+def conv_silu(x, w, b, L):
+    """x (T, C), w (C, 4), b (C): causal depthwise conv over each length-L sequence, then SiLU."""
+    return _ConvSilu.apply(x, w, b, L)
+
+
+class _Scan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H):
+        _need_cuda(xc, z, dbc)
+        xc, dbc, Wdt, bdt, A_log, D = (_f32c(t) for t in (xc, dbc, Wdt, bdt, A_log, D))
+        z = _f32c(z) if z is not None else None
+        T, C = xc.shape
+        B = T // L
+        if ED < 32 or ED & (ED - 1) or C != ED * H:
+            raise hmx.HmxError(f"selective scan needs 4*head_dim to be a power of two >= 32 (got {ED})")
+        keep = any(ctx.needs_input_grad)
+        hs = _empty(T, C, N_STATE, like=xc) if keep else None
+        yg = torch.empty_like(xc)
+        hmx.check(_L().hmx_scan_fwd(hmx.ptr(xc), hmx.ptr(z), hmx.ptr(dbc), hmx.ptr(Wdt), hmx.ptr(bdt), hmx.ptr(A_log),
+                                    hmx.ptr(D), B, L, C, ED, H, hmx.ptr(yg), hmx.ptr(hs), _s()), "hmx_scan_fwd")
+        if keep:
+            ctx.save_for_backward(xc, z, dbc, Wdt, bdt, A_log, D, hs)
+        ctx.dims = (B, L, C, ED, H)
+        return yg
+
+    @staticmethod
+    def backward(ctx, dyg):
+        xc, z, dbc, Wdt, bdt, A_log, D, hs = ctx.saved_tensors
+        B, L, C, ED, H = ctx.dims
+        T = B * L
+        dyg = _f32c(dyg)
+        gph = _L().hmx_scan_groups_per_head(ED)
+        dxc = torch.empty_like(xc)
+        dz = torch.empty_like(z) if z is not None else None
+        dpart = _empty(T * H, gph, P_DBC, like=xc)
+        ppart = _empty(B, C * 34, like=xc)
+        hmx.check(_L().hmx_scan_bwd(hmx.ptr(xc), hmx.ptr(z), hmx.ptr(dbc), hmx.ptr(Wdt), hmx.ptr(bdt), hmx.ptr(A_log),
+                                    hmx.ptr(D), hmx.ptr(hs), hmx.ptr(dyg), B, L, C, ED, H, hmx.ptr(dxc), hmx.ptr(dz),
+                                    hmx.ptr(dpart), hmx.ptr(ppart), _s()), "hmx_scan_bwd")
+        if gph == 1:
+            ddbc = dpart.view(T, H * P_DBC)
+        else:
+            ddbc = _empty(T, H * P_DBC, like=xc)
+            hmx.check(_L().hmx_sum_groups_f32(hmx.ptr(dpart), T * H, gph, P_DBC, hmx.ptr(ddbc), _s()),
+                      "hmx_sum_groups_f32")
+        pg = colsum(ppart).view(C, 34)
+        return (dxc, dz, ddbc, pg[:, 16:32].contiguous(), pg[:, 32].contiguous(), pg[:, :16].contiguous(),
+                pg[:, 33].contiguous(), None, None, None)
+
+
+def selective_scan_gated(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H):
+    """(scan(xc; dbc, params) + D xc) * SiLU(z) for all heads (z = None: no gate); see hmx_scan_fwd."""
+    return _Scan.apply(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H)
+
+
+def seq_index(ids, ts, time_span):
+    """(B, L) ids / timestamps -> padding mask (T,) float, position ids (T,), time bins (T,) (no gradient)."""
+    _need_cuda(ids, ts)
+    ids, ts = _i64c(ids), _i64c(ts)
+    B, L = ids.shape
+    T = B * L
+    mask = torch.empty(T, dtype=torch.float32, device=ids.device)
+    pos = torch.empty(T, dtype=torch.int64, device=ids.device)
+    tb = torch.empty(T, dtype=torch.int64, device=ids.device)
+    hmx.check(_L().hmx_seq_index(hmx.ptr(ids), hmx.ptr(ts), T, L, time_span, hmx.ptr(mask), hmx.ptr(pos), hmx.ptr(tb),
+                                 _s()), "hmx_seq_index")
+    return mask, pos, tb

@@ -4,13 +4,14 @@ There is no CPU fallback: if the library is missing or a call fails, this raises
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhmx.so")
 
 P = c_void_p
 I64 = c_int64
+F = c_float
 
 # name -> (restype, argtypes); must list every symbol declared in include/hmx.h
 PROTOTYPES = {
@@ -25,6 +26,26 @@ PROTOTYPES = {
     "hmx_score_topk_f32": (c_int, [P, I64, P, I64, I64, I64, P, I64, I64, P, P, P, c_size_t, P]),
     "hmx_score_topk_bf16": (c_int, [P, I64, P, P, P, I64, I64, I64, P, I64, I64, P, P, P, P, c_size_t, P]),
     "hmx_topk_merge": (c_int, [P, P, I64, I64, I64, P, P, P]),
+    "hmx_rmsnorm_fwd": (c_int, [P, P, I64, I64, F, P, P, P]),
+    "hmx_rmsnorm_bwd_blocks": (I64, [I64]),
+    "hmx_rmsnorm_bwd": (c_int, [P, P, P, P, I64, I64, P, P, P]),
+    "hmx_colsum_f32": (c_int, [P, I64, I64, I64, P, P]),
+    "hmx_set_linear_precision": (c_int, [c_int]),
+    "hmx_linear_f32": (c_int, [P, I64, P, I64, I64, P, I64, I64, I64, P, I64, P, I64, F, P, I64, F, P, P, c_int, P]),
+    "hmx_linear_wgrad_workspace_bytes": (c_size_t, [I64, I64, I64]),
+    "hmx_linear_wgrad_f32": (c_int, [P, I64, P, I64, P, I64, I64, I64, P, I64, P, P, c_size_t, P]),
+    "hmx_silu_rope_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, P, P]),
+    "hmx_silu_rope_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, P, P]),
+    "hmx_binary_fwd": (c_int, [P, P, I64, F, c_int, P, P]),
+    "hmx_binary_bwd": (c_int, [P, P, P, I64, F, c_int, P, P, P]),
+    "hmx_combine_f32": (c_int, [P, P, P, P, F, F, F, F, P, I64, I64, P, P]),
+    "hmx_seq_index": (c_int, [P, P, I64, I64, I64, P, P, P, P]),
+    "hmx_conv_silu_fwd": (c_int, [P, P, P, I64, I64, I64, P, P]),
+    "hmx_conv_silu_bwd": (c_int, [P, P, P, P, I64, I64, I64, P, P, P]),
+    "hmx_scan_fwd": (c_int, [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P]),
+    "hmx_scan_groups_per_head": (I64, [I64]),
+    "hmx_scan_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, P]),
+    "hmx_sum_groups_f32": (c_int, [P, I64, I64, I64, P, P]),
     "hmx_profile_enable": (c_int, [c_int]),
     "hmx_profile_collect": (c_int, [c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }
@@ -77,3 +98,8 @@ def profile_collect(tag):
     ms, n = ctypes.c_double(0.0), c_int64(0)
     check(lib().hmx_profile_collect(tag.encode(), ctypes.byref(ms), ctypes.byref(n)), "hmx_profile_collect")
     return ms.value, n.value
+
+
+def set_linear_precision(split_bf16=True):
+    """True (default): split-bf16 projections (fp32-class accuracy); False: single bf16 MFMA per product."""
+    check(lib().hmx_set_linear_precision(1 if split_bf16 else 0), "hmx_set_linear_precision")

@@ -1,0 +1,468 @@
+"""Drop-in modules for hydra3.py on the MI355X kernels of libhmx.so.
+
+Class names, constructor arguments, parameter names / shapes and forward signatures follow the reference
+(hydra3.py:158-720, 978-1151) so that a reference state_dict loads with strict=True and main.py / infer.py
+call sites keep working; the computation runs in the HIP kernels (enc_ops / ops).  CUDA fp32 only.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import enc_ops as E
+from . import ops
+from .shared_embedding import SharedEmbeddingConfig, SharedEmbeddingModule
+
+D_STATE, DT_RANK, D_CONV = 16, 16, 4
+
+
+class RMSNorm(nn.Module):
+    """hydra3.py:221-229."""
+
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.eps = eps
+        self.scale = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return E.rmsnorm(x.reshape(-1, x.shape[-1]), self.scale, self.eps).view(x.shape)
+
+
+class SSM(nn.Module):
+    """hydra3.py:158-218 (parameters; the fused scan kernel consumes them)."""
+
+    def __init__(self, in_features, dt_rank, dim_inner, d_state):
+        super().__init__()
+        assert dt_rank == DT_RANK and d_state == D_STATE, "kernels are built for dt_rank = d_state = 16"
+        self.dt_rank, self.dim_inner, self.d_state = dt_rank, dim_inner, d_state
+        self.deltaBC_layer = nn.Linear(in_features, dt_rank + 2 * d_state, bias=False)
+        self.dt_proj_layer = nn.Linear(dt_rank, dim_inner, bias=True)
+        self.A_log = nn.Parameter(torch.log(torch.arange(1, d_state + 1, dtype=torch.float32)).repeat(dim_inner, 1))
+        self.D = nn.Parameter(torch.ones(dim_inner))
+
+    def forward(self, x, pscan=True):
+        B, L, ED = x.shape
+        xc = x.reshape(B * L, ED)
+        dbc = E.heads_linear(xc, [self.deltaBC_layer.weight])
+        y = E.selective_scan_gated(xc, None, dbc, self.dt_proj_layer.weight, self.dt_proj_layer.bias, self.A_log,
+                                   self.D, L, ED, 1)
+        return y.view(B, L, ED)
+
+
+class MambaBlock(nn.Module):
+    """hydra3.py:232-277."""
+
+    def __init__(self, dim, dt_rank, dim_inner, d_state, d_conv=D_CONV):
+        super().__init__()
+        assert d_conv == D_CONV
+        self.dim, self.dim_inner, self.d_conv = dim, dim_inner, d_conv
+        self.in_proj = nn.Linear(dim, dim_inner * 2, bias=False)
+        self.conv1d = nn.Conv1d(dim_inner, dim_inner, d_conv, groups=dim_inner, padding=d_conv - 1, bias=True)
+        self.activation = nn.SiLU()
+        self.ssm = SSM(dim_inner, dt_rank, dim_inner, d_state)
+        self.out_proj = nn.Linear(dim_inner, dim, bias=False)
+
+    def forward(self, x):
+        B, L, dim = x.shape
+        return mamba_heads([self], x.reshape(B * L, dim), L).view(B, L, dim)
+
+
+def mamba_heads(blocks, s, L):
+    """All heads' MambaBlocks at once.  s: (T, H*hd) -> (T, H*hd)."""
+    ED, H = blocks[0].dim_inner, len(blocks)
+    x_in = E.heads_linear(s, [m.in_proj.weight[:ED] for m in blocks])
+    z = E.heads_linear(s, [m.in_proj.weight[ED:] for m in blocks])
+    one = H == 1
+    cat = (lambda ts: ts[0]) if one else torch.cat
+    xc = E.conv_silu(x_in, cat([m.conv1d.weight.view(ED, D_CONV) for m in blocks]),
+                     cat([m.conv1d.bias for m in blocks]), L)
+    dbc = E.heads_linear(xc, [m.ssm.deltaBC_layer.weight for m in blocks])
+    yg = E.selective_scan_gated(xc, z, dbc, cat([m.ssm.dt_proj_layer.weight for m in blocks]),
+                                cat([m.ssm.dt_proj_layer.bias for m in blocks]), cat([m.ssm.A_log for m in blocks]),
+                                cat([m.ssm.D for m in blocks]), L, ED, H)
+    return E.heads_linear(yg, [m.out_proj.weight for m in blocks])
+
+
+class MultiHeadMamba(nn.Module):
+    """hydra3.py:280-389."""
+
+    def __init__(self, dim, dt_rank, dim_inner, d_state, args):
+        super().__init__()
+        self.args = args
+        self.head_dim = dim // args.hydra_num_heads
+        assert self.head_dim % 2 == 0, "Head dimension must be even for RoPE"       # hydra3.py:315
+        self.mamba = nn.ModuleList([MambaBlock(self.head_dim, dt_rank, 4 * self.head_dim, d_state)
+                                    for _ in range(args.hydra_num_heads)])
+        self.activation = nn.SiLU()
+        self.linear_layer1 = nn.Linear(dim, dim)
+        self.linear_layer2 = nn.Linear(dim, dim)
+
+    def mix(self, x2, mask1, L):
+        """x2 (T, d) -> W2-input p = y1 * y2 / sqrt(H)."""
+        x1 = E.linear(x2, self.linear_layer1.weight, self.linear_layer1.bias, in_mask=mask1)
+        s, y2 = E.silu_rope(x1, L, self.head_dim)
+        y1 = mamba_heads(list(self.mamba), s, L)
+        return E.mul_scale(y1, y2, 1.0 / math.sqrt(len(self.mamba)))
+
+    def forward(self, x, x_org, padding_mask):
+        B, L, d = x.shape
+        m1 = padding_mask.reshape(B * L) if padding_mask is not None else None
+        p = self.mix(x.reshape(B * L, d), m1, L)
+        out = E.linear(p, self.linear_layer2.weight, self.linear_layer2.bias, r1=x_org.reshape(B * L, d), c1=1.0)
+        return out.view(B, L, d)
+
+
+class _HydraBlockBase(nn.Module):
+    first = False
+
+    def __init__(self, dim, dt_rank, dim_inner, d_state, args):
+        super().__init__()
+        self.multiheadMamba = MultiHeadMamba(dim, dt_rank, dim_inner, d_state, args)
+        self.gate = nn.Linear(dim, dim, bias=False)
+        self.up = nn.Linear(dim, dim, bias=False)
+        self.down = nn.Linear(dim, dim, bias=False)
+        self.activation = nn.SiLU()
+        self.dropout = nn.Dropout(p=args.hydra_dropout_rate)
+        self.norm1 = RMSNorm(dim)
+        self.norm2 = RMSNorm(dim)
+
+    def forward(self, x, padding_mask):
+        B, L, d = x.shape
+        T = B * L
+        x2 = x.reshape(T, d)
+        m1 = padding_mask.reshape(T).contiguous() if padding_mask is not None else None
+        mhm = self.multiheadMamba
+        n = E.rmsnorm(self.dropout(x2), self.norm1.scale, self.norm1.eps)
+        p = mhm.mix(n, m1, L)
+        # mixer output x_org + W2 p + b2, plus the block's residual: n (first block) or x again (regular block)
+        if self.first:
+            m = E.linear(p, mhm.linear_layer2.weight, mhm.linear_layer2.bias, r1=x2, c1=1.0, r2=n, c2=1.0)
+        else:
+            m = E.linear(p, mhm.linear_layer2.weight, mhm.linear_layer2.bias, r1=x2, c1=2.0)
+        n2 = E.rmsnorm(m, self.norm2.scale, self.norm2.eps)
+        hmid = E.swiglu(E.linear(n2, self.gate.weight), E.linear(n2, self.up.weight))
+        out = E.linear(hmid, self.down.weight, r1=n2 if self.first else m, c1=1.0, out_mask=m1)
+        return out.view(B, L, d)
+
+
+class HydraBlockFirst(_HydraBlockBase):
+    """hydra3.py:392-423."""
+    first = True
+
+
+class HydraBlock(_HydraBlockBase):
+    """hydra3.py:426-457."""
+    first = False
+
+
+class MultiScaleUserEncoder(nn.Module):
+    """hydra3.py:460-548.  The three HydraBlocks run on the HIP kernels; the one-query fusion tail (B x 1 tokens)
+    is composed of PyTorch ops."""
+
+    def __init__(self, dim, dt_rank, dim_inner, d_state, args):
+        super().__init__()
+        self.args, self.hidden_dim = args, dim
+        self.short_term_encoder = HydraBlock(dim, dt_rank, dim_inner, d_state, args)
+        self.mid_term_encoder = HydraBlock(dim, dt_rank, dim_inner, d_state, args)
+        self.long_term_encoder = HydraBlock(dim, dt_rank, dim_inner, d_state, args)
+        self.cross_attention = nn.MultiheadAttention(dim, args.hydra_num_heads, dropout=args.hydra_dropout_rate,
+                                                     batch_first=True)
+        self.fusion_gate = nn.Sequential(nn.Linear(dim * 3, dim), nn.Sigmoid())
+        self.output_proj = nn.Linear(dim, dim)
+        self.norm = RMSNorm(dim)
+
+    def forward(self, sequence, padding_mask=None):
+        L = sequence.shape[1]
+        sw, mw = min(10, L), min(25, L)
+        sm = padding_mask[:, -sw:].contiguous() if padding_mask is not None else None
+        mm = padding_mask[:, -mw:].contiguous() if padding_mask is not None else None
+        short = self.short_term_encoder(sequence[:, -sw:].contiguous(), sm)
+        mid = self.mid_term_encoder(sequence[:, -mw:].contiguous(), mm)
+        long_ = self.long_term_encoder(sequence, padding_mask)
+        sf, mf, lf = short[:, -1:], mid[:, -1:], long_[:, -1:]
+        att, _ = self.cross_attention(query=sf, key=long_, value=long_, need_weights=False)
+        g = self.fusion_gate(torch.cat([sf, mf, lf], dim=-1))
+        fused = self.output_proj(self.norm(g * att + (1 - g) * lf))
+        return long_ + 0.5 * fused
+
+
+class PositionAwareEncoder(nn.Module):
+    """hydra3.py:1044-1082: constructed by Hydra but never called; its parameters exist for state_dict parity."""
+
+    def __init__(self, hidden_dim, max_len=512):
+        super().__init__()
+        self.hidden_dim, self.max_len = hidden_dim, max_len
+        self.position_weights = nn.Parameter(torch.ones(max_len))
+        self.position_attention = nn.MultiheadAttention(hidden_dim, 2, dropout=0.2, batch_first=True)
+
+
+class AdaptiveHardNegativeSampler(nn.Module):
+    """hydra3.py:1024-1041."""
+
+    def __init__(self, initial_ratio=0.3, max_ratio=0.7):
+        super().__init__()
+        self.initial_ratio, self.max_ratio = initial_ratio, max_ratio
+        self.register_buffer('training_step', torch.tensor(0.0))
+
+    def get_current_ratio(self, max_steps=10000):
+        progress = min(float(self.training_step) / max_steps, 1.0)
+        return self.initial_ratio + (self.max_ratio - self.initial_ratio) * progress
+
+    def update_step(self):
+        self.training_step += 1
+
+
+class HardNegativeMiner:
+    """hydra3.py:978-1007 on the fused HIP scoring + top-K: no (B, items) score matrix is formed."""
+
+    def __init__(self, model, item_embeddings, top_k=100, prepared=None):
+        self.model, self.item_embeddings, self.top_k = model, item_embeddings, top_k
+        self.prepared = prepared
+
+    @torch.no_grad()
+    def mine_hard_negatives_similarity(self, user_embeddings, positive_items, exclude_items=None):
+        prepared = self.prepared if self.prepared is not None else ops.PreparedTable(self.item_embeddings.detach())
+        excl = [t.reshape(t.shape[0], -1) for t in (positive_items, exclude_items) if t is not None]
+        excl = torch.cat(excl, dim=1) if excl else None
+        ids, _ = ops.score_topk(user_embeddings.detach(), prepared, self.top_k, exclude=excl)
+        return ids
+
+
+def _sample_inbatch_indices_no_self(M, rows, T, device):
+    """hydra3.py:817-830."""
+    r = torch.randint(0, M - 1, (rows.size(0), T), device=device)
+    return r + (r >= rows.unsqueeze(1)).long()
+
+
+def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=None, hard_negatives=None, T=512,
+                                   hard_ratio=0.3, temperature=0.05, normalize=True, q_chunk=64, device=None):
+    """hydra3.py:845-974 (InfoNCE over in-batch + hard negatives).  PyTorch ops on the GPU, except the hard-negative
+    row gather `item_table[ids]` (hydra3.py:917), which is the HIP gather with its scatter-add backward."""
+    device = log_feats.device
+    mask = loss_mask.bool()
+    q, k = log_feats[mask], pos_embs[mask]
+    M = q.shape[0]
+    if M == 0:
+        return torch.tensor(0.0, device=device, requires_grad=True)
+    if normalize:
+        q, k = F.normalize(q, p=2, dim=-1), F.normalize(k, p=2, dim=-1)
+    num_hard = int(T * hard_ratio)
+    num_inb = T - num_hard
+    hard_ids = hard_negatives[mask] if hard_negatives is not None else None
+    rows = torch.arange(M, device=device)
+    losses = []
+    for s in range(0, M, q_chunk):
+        e = min(s + q_chunk, M)
+        n = e - s
+        negs = []
+        if hard_ids is not None and num_hard > 0:
+            ch = hard_ids[s:e]
+            K = ch.shape[1]
+            if K >= num_hard:
+                ch = torch.gather(ch, 1, torch.randint(0, K, (n, num_hard), device=device))
+            else:
+                ch = ch.repeat(1, (num_hard + K - 1) // K)[:, :num_hard]
+            hn = ops.gather_rows(item_table, ch.contiguous())
+            negs.append(F.normalize(hn, p=2, dim=-1) if normalize else hn)
+        if num_inb > 0:
+            if M - 1 >= num_inb:
+                inb = k[_sample_inbatch_indices_no_self(M, rows[s:e], num_inb, device)]
+            else:
+                base = torch.arange(M, device=device).unsqueeze(0).repeat(M, 1)
+                inb = k[base[base != rows.unsqueeze(1)].view(M, M - 1)[s:e]]
+                short = num_inb - inb.shape[1]
+                if short > 0:
+                    if item_table is not None:
+                        rid = torch.randint(1, item_table.shape[0], (n, short), device=device)
+                        re_ = ops.gather_rows(item_table, rid)
+                        inb = torch.cat([inb, F.normalize(re_, p=2, dim=-1) if normalize else re_], dim=1)
+                    else:
+                        inb = torch.cat([inb, inb[:, -1:].expand(-1, short, -1)], dim=1)
+            negs.append(inb)
+        keys = torch.cat([k[s:e].unsqueeze(1)] + negs, dim=1)
+        logits = (q[s:e].unsqueeze(1) * keys).sum(-1) / temperature
+        losses.append(-F.log_softmax(logits, dim=1)[:, 0])
+    return torch.cat(losses, dim=0).mean()
+
+
+class EnhancedTrainingLoss(nn.Module):
+    """hydra3.py:1085-1151."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.ranking_loss_weight = getattr(args, 'ranking_loss_weight', 0.0)
+        self.contrastive_loss_weight = getattr(args, 'contrastive_loss_weight', 1.0)
+        self.diversity_loss_weight = getattr(args, 'diversity_loss_weight', 0.0)
+        self.q_chunk = getattr(args, 'loss_q_chunk', 256)          # hydra3.py:1132
+        self.adaptive_hard_sampler = AdaptiveHardNegativeSampler()
+
+    def forward(self, user_embs, pos_embs, neg_embs, hard_negatives, loss_mask, item_table):
+        total = self.contrastive_loss_weight * compute_mixed_contrastive_loss(
+            user_embs, pos_embs, loss_mask, item_table, hard_negatives, hard_ratio=0.3, T=512, temperature=0.05,
+            q_chunk=self.q_chunk)
+        self.adaptive_hard_sampler.update_step()
+        if neg_embs is not None and self.ranking_loss_weight != 0.0:
+            u, p, n, lm = user_embs[:, -1], pos_embs[:, -1], neg_embs[:, -1], loss_mask[:, -1]
+            rl = -F.logsigmoid((u * p).sum(-1) - (u * n).sum(-1))
+            total = total + self.ranking_loss_weight * ((rl * lm).sum() / lm.sum())
+        if self.diversity_loss_weight != 0.0:
+            un = F.normalize(user_embs[:, -1], p=2, dim=1)
+            sim = un @ un.t()
+            total = total + self.diversity_loss_weight * (sim * (1 - torch.eye(sim.shape[0], device=sim.device))).abs().mean()
+        return total
+
+
+class Hydra(nn.Module):
+    """hydra3.py:553-720 (ids-only feature configuration)."""
+
+    def __init__(self, user_num, item_num, feat_statistics, feat_types, args, shared_embeddings=None):
+        super().__init__()
+        self.user_num, self.item_num, self.dev = user_num, item_num, args.device
+        self.norm_first, self.maxlen, self.args = args.norm_first, args.maxlen, args
+        if shared_embeddings is not None:
+            self.shared_embeddings = shared_embeddings
+        else:
+            SharedEmbeddingConfig(args)
+            self.shared_embeddings = SharedEmbeddingModule(user_num, item_num, feat_statistics, feat_types, args)
+        d = args.hydra_hidden_units
+        if args.shared_hidden_units != d:
+            self.embedding_projection = nn.Linear(args.shared_hidden_units, d)
+        else:
+            self.embedding_projection = nn.Identity()
+        self.hydra_projection = nn.Linear(args.shared_hidden_units * 2, d)
+        if not hasattr(self.shared_embeddings, 'hydra_projection'):
+            self.shared_embeddings.hydra_projection = self.hydra_projection
+        self.time_span_emb = nn.Embedding(getattr(args, 'time_span', 512), d, padding_idx=0)   # unused (hydra3.py:580)
+        self.hydra = nn.ModuleList()
+        self.multi_scale_encoder = MultiScaleUserEncoder(d, DT_RANK, 4 * d, D_STATE, args)
+        self.hidden_units = d
+        for _ in range(args.hydra_num_blocks):
+            self.hydra.append(HydraBlock(d, DT_RANK, 4 * d, D_STATE, args))
+        self.hydra_first = HydraBlockFirst(d, DT_RANK, 4 * d, D_STATE, args)
+        self.position_aware_encoder = PositionAwareEncoder(d, max_len=args.maxlen + 1)
+        self.enchanced_loss = EnhancedTrainingLoss(args)
+        self._prepared = None
+
+    # ---- input assembly (hydra3.py:621-669) --------------------------------------------------
+    def _project_small(self, rows):
+        if isinstance(self.embedding_projection, nn.Identity):
+            return rows
+        return E.linear(rows, self.embedding_projection.weight, self.embedding_projection.bias)
+
+    def _project_ids(self, base):
+        """hydra_projection applied to cat[base, 0]: only the first half of the weight's columns contributes."""
+        return E.linear(base, self.hydra_projection.weight, self.hydra_projection.bias)
+
+    def assemble_inputs(self, log_seqs, mask, seq_timestamp, action_type, dwell_bins):
+        se = self.shared_embeddings
+        B, L = log_seqs.shape
+        T = B * L
+        pm, pos, tb = E.seq_index(log_seqs, seq_timestamp, getattr(self.args, 'time_span', 512))
+        base = ops.gather_routed(se.item_emb.weight, se.user_emb.weight, log_seqs.reshape(T), mask.reshape(T))
+        e = E.combine_ad([base, ops.gather_rows(se.pos_emb.weight, pos, 0)], [1.0, 1.0])
+        proj = self._project_ids(e)
+        t_rows = self._project_small(ops.gather_rows(se.time_span_emb.weight, tb, 0))
+        a_rows = self._project_small(ops.gather_rows(se.action_emb.weight, action_type.reshape(T), 0))
+        d_rows = self._project_small(ops.gather_rows(se.dwell_time_emb.weight, dwell_bins.reshape(T), 0))
+        seqs = E.combine_ad([proj, t_rows, a_rows, d_rows],
+                            [self.args.hydra_hidden_units ** 0.5, 1.0, 1.0, 1.0], rowmask=pm)
+        return seqs.view(B, L, -1), pm.view(B, L, 1)
+
+    def log2feats(self, log_seqs, seq_feature, mask, seq_timestamp, action_type, dwell_bins):
+        """hydra3.py:618-681."""
+        if log_seqs.shape[1] > self.maxlen + 1:                          # hydra3.py:623-626
+            cut = -self.maxlen - 1
+            log_seqs, mask, seq_timestamp = log_seqs[:, cut:], mask[:, cut:], seq_timestamp[:, cut:]
+            action_type, dwell_bins = action_type[:, cut:], dwell_bins[:, cut:]
+        seqs, pm = self.assemble_inputs(log_seqs, mask, seq_timestamp, action_type, dwell_bins)
+        seqs = self.hydra_first(seqs, padding_mask=pm)
+        for blk in self.hydra:
+            seqs = blk(x=seqs, padding_mask=pm)
+        seqs = self.multi_scale_encoder(seqs, pm)
+        return seqs * pm
+
+    def get_user_embedding(self, seq, seq_feat, token_type, seq_timestamp, action_type, dwell_bins):
+        """hydra3.py:808-815."""
+        return self.log2feats(seq, seq_feat, token_type, seq_timestamp, action_type, dwell_bins)[:, -1, :]
+
+    def predict(self, log_seqs, seq_feature, mask, seq_timestamp, action_type, dwell_bins):
+        """hydra3.py:722-728 (with the dwell_bins argument the reference's call sites pass)."""
+        return self.get_user_embedding(log_seqs, seq_feature, mask, seq_timestamp, action_type, dwell_bins)
+
+    def prepared_item_table(self, refresh=True):
+        """bf16 scoring copy of the item table (rebuilt after every optimizer step while training)."""
+        w = self.shared_embeddings.item_emb.weight.detach()
+        if self._prepared is None or self._prepared.table.data_ptr() != w.data_ptr():
+            self._prepared = ops.PreparedTable(w)
+        elif refresh:
+            self._prepared.refresh()
+        return self._prepared
+
+    def forward(self, user_item, pos_seqs, neg_seqs, mask, next_mask, next_action_type, seq_feature, pos_feature,
+                neg_feature, timestamp, action_type, dwell_bins):
+        """hydra3.py:683-720."""
+        log_feats = self.log2feats(user_item, seq_feature, mask, timestamp, action_type, dwell_bins)
+        se = self.shared_embeddings
+        item_table = se.item_emb.weight
+        B, L = pos_seqs.shape
+        pos_embs = self._project_ids(se.item_emb(pos_seqs.reshape(B * L))).view(B, L, -1)
+        neg_embs = None
+        if self.enchanced_loss.ranking_loss_weight != 0.0:
+            neg_embs = self._project_ids(se.item_emb(neg_seqs.reshape(B * L))).view(B, L, -1)
+        miner = HardNegativeMiner(self, item_table, top_k=50, prepared=self.prepared_item_table())
+        hard = miner.mine_hard_negatives_similarity(log_feats[:, -1, :], positive_items=pos_seqs,
+                                                    exclude_items=user_item)
+        hard = hard.unsqueeze(1).expand(-1, log_feats.shape[1], -1)
+        return self.enchanced_loss(user_embs=log_feats, pos_embs=pos_embs, neg_embs=neg_embs, hard_negatives=hard,
+                                   loss_mask=(next_mask == 1), item_table=item_table)
+
+
+IDS_ONLY_FEAT_TYPES = {k: [] for k in ('user_sparse', 'item_sparse', 'user_array', 'item_array',
+                                        'user_continual', 'item_continual', 'item_emb')}
+
+
+def make_args(d=64, L=100, heads=2, blocks=2, dropout=0.2, device='cuda', **kw):
+    from types import SimpleNamespace
+    a = SimpleNamespace(device=device, hydra_hidden_units=d, hstu_hidden_units=d, shared_hidden_units=d,
+                        hydra_num_heads=heads, hydra_num_blocks=blocks, hydra_dropout_rate=dropout, maxlen=L - 1,
+                        norm_first=False, num_actions=5, time_span=512)
+    a.__dict__.update(kw)
+    return a
+
+
+def build_model(n_users, n_items, d=64, L=100, heads=2, blocks=2, dropout=0.2, device='cuda', seed=0, **kw):
+    """Ids-only Hydra initialised as main.py:603-607,619-622 (xavier_normal_ on >= 2-D parameters, zero padding rows)."""
+    args = make_args(d, L, heads, blocks, dropout, device, **kw)
+    torch.manual_seed(seed)
+    se = SharedEmbeddingModule(n_users, n_items, {}, IDS_ONLY_FEAT_TYPES, args, None)
+    model = Hydra(n_users, n_items, {}, IDS_ONLY_FEAT_TYPES, args, se)
+    for p in model.parameters():
+        if p.dim() >= 2:
+            nn.init.xavier_normal_(p.data)
+    for t in (se.pos_emb, se.item_emb, se.user_emb, se.action_emb):
+        t.weight.data[0].zero_()
+    return model.to(device)
+
+
+def smoke(dev):
+    """Tiny forward + backward of the whole model on `dev`, checked against the CPU oracle."""
+    from oracle import hydra_oracle as O
+    from . import synth
+    U, I, d, L, B = 50, 300, 64, 12, 4
+    ref = O.build_model(U, I, d=d, L=L, dropout=0.0, seed=3)
+    model = Hydra(U, I, {}, IDS_ONLY_FEAT_TYPES, make_args(d, L, dropout=0.0, device=str(dev)),
+                  SharedEmbeddingModule(U, I, {}, IDS_ONLY_FEAT_TYPES, make_args(d, L, dropout=0.0, device=str(dev))))
+    model.load_state_dict(ref.state_dict(), strict=True)
+    model.to(dev)
+    bt = synth.train_batch(B, L, U, I, "cpu", seed=5, pad_frac=0.3)
+    feat = [[] for _ in range(B)]
+    want = ref.log2feats(bt["seq"], feat, bt["tok"], bt["ts"], bt["act"], bt["dwell"])
+    g = {k: v.to(dev) for k, v in bt.items()}
+    got = model.log2feats(g["seq"], feat, g["tok"], g["ts"], g["act"], g["dwell"])
+    err = (got.detach().cpu() - want.detach()).abs().max().item()
+    scale = want.detach().abs().max().item()
+    assert err <= 0.03 * scale + 1e-3, f"log2feats mismatch: {err} vs scale {scale}"
+    got.square().mean().backward()
+    assert model.shared_embeddings.item_emb.weight.grad is not None

@@ -108,11 +108,96 @@ int hmx_score_topk_bf16(const float* queries, int64_t n_q, const float* table, c
 int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_shards, int64_t n_q, int64_t k,
                    int64_t* out_ids, float* out_scores, void* stream);
 
+/* =================================================================================
+ * Sequence encoder (hydra3.py).  Activations are (T = B*L tokens, features) row-major fp32.
+ * Forward and backward of every stage; the Python modules chain them under autograd.
+ * ================================================================================= */
+
+/* RMSNorm, y = x / sqrt(mean(x^2) + eps) * scale (hydra3.py:221-229).  rstd (T) is kept for the
+ * backward pass (may be NULL).  Backward writes dx and per-block partials of dscale, shaped
+ * (hmx_rmsnorm_bwd_blocks(T), d); their column sums (hmx_colsum_f32) are dscale.  d <= 256. */
+int hmx_rmsnorm_fwd(const float* x, const float* scale, int64_t T, int64_t d, float eps, float* y, float* rstd,
+                    void* stream);
+int64_t hmx_rmsnorm_bwd_blocks(int64_t T);
+int hmx_rmsnorm_bwd(const float* x, const float* scale, const float* rstd, const float* dy, int64_t T, int64_t d,
+                    float* dx, float* dscale_part, void* stream);
+
+/* out[c] = sum_r P[r * ld + c], fixed summation order (reduction of per-block / per-sequence partials). */
+int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_t ld, float* out, void* stream);
+
+/* Dense projection on bf16 MFMA with fp32 accumulate (nn.Linear / F.linear at hydra3.py:206,210,263,
+ * 275,366,388,416-418,643 and their dgrad):
+ *   Y[t, n] = ( sum_k X[t, k] * in_rowmask[t] * Wv(n, k) + bias[n] + c1 R1[t, n] + c2 R2[t, n] ) * out_rowmask[t]
+ * with Wv(n, k) = W[n * w_rs + k * w_cs] (w_rs = K, w_cs = 1 for a forward product with an (N, K) weight;
+ * w_rs = 1, w_cs = ld for the transposed product of the backward pass).  Any of bias, R1, R2, the masks
+ * may be NULL.  accumulate != 0 adds the result to Y.  K <= 256.
+ * Precision (process-wide, hmx_set_linear_precision): split_bf16 = 1 (default) writes every operand as a sum of
+ * two bf16 numbers and accumulates hi*hi + lo*hi + hi*lo on the MFMA (fp32-class accuracy, three MFMAs per
+ * product); split_bf16 = 0 rounds operands to one bf16 (relative error ~2^-9 per operand, one MFMA). */
+int hmx_set_linear_precision(int split_bf16);
+int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, int64_t w_cs, const float* bias,
+                   int64_t T, int64_t N, int64_t K, float* Y, int64_t ldy, const float* R1, int64_t ldr1, float c1,
+                   const float* R2, int64_t ldr2, float c2, const float* in_rowmask, const float* out_rowmask,
+                   int accumulate, void* stream);
+
+/* Weight / bias gradient on fp32 MFMA: dW[n * ldw + k] = sum_t dY[t, n] * X[t, k] * in_rowmask[t],
+ * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  Deterministic two-stage reduction over tokens. */
+size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K);
+int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, const float* in_rowmask, int64_t T,
+                         int64_t N, int64_t K, float* dW, int64_t ldw, float* dbias, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* s = SiLU(x1); y2 = RoPE(s) on interleaved pairs per head, position = t mod L, angle tables cos/sin of
+ * shape (L, hd/2) (hydra3.py:300-357, 368, 381-386).  Backward: dx1 = (ds + RoPE^T(dy2)) * SiLU'(x1). */
+int hmx_silu_rope_fwd(const float* x1, const float* cos_t, const float* sin_t, int64_t T, int64_t L, int64_t d,
+                      int64_t hd, float* s, float* y2, void* stream);
+int hmx_silu_rope_bwd(const float* x1, const float* cos_t, const float* sin_t, const float* ds, const float* dy2,
+                      int64_t T, int64_t L, int64_t d, int64_t hd, float* dx1, void* stream);
+
+/* mode 0: out = a * b * c (y1 * y2 / sqrt(H), hydra3.py:387);  mode 1: out = SiLU(a) * b (hydra3.py:416-418). */
+int hmx_binary_fwd(const float* a, const float* b, int64_t n, float c, int mode, float* out, void* stream);
+int hmx_binary_bwd(const float* a, const float* b, const float* g, int64_t n, float c, int mode, float* da, float* db,
+                   void* stream);
+
+/* out[t, :] = (c0 x0 + c1 x1 + c2 x2 + c3 x3)[t, :] * rowmask[t]; x1..x3 and rowmask may be NULL
+ * (the sums and mask of hydra3.py:647-669 and the mask / coefficient steps of the backward pass). */
+int hmx_combine_f32(const float* x0, const float* x1, const float* x2, const float* x3, float c0, float c1, float c2,
+                    float c3, const float* rowmask, int64_t T, int64_t d, float* out, void* stream);
+
+/* Index preparation of log2feats (hydra3.py:621-659): mask[t] = (id != 0), pos_idx = (l + 1) * (id != 0),
+ * time_bin = min(floor(ln(dt + 1)), time_span - 1) * (id != 0), dt = ts[t] - ts[t-1] unless t starts a
+ * sequence or follows a padding token. */
+int hmx_seq_index(const int64_t* ids, const int64_t* ts, int64_t T, int64_t L, int64_t time_span, float* mask,
+                  int64_t* pos_idx, int64_t* time_bin, void* stream);
+
+/* Causal depthwise conv (kernel 4) + bias + SiLU over x (T, C), weights w (C, 4), b (C)
+ * (nn.Conv1d at hydra3.py:243-250 with the slice at :267, SiLU at :269).  Backward writes dx and
+ * per-sequence partials part (B, C, 5) = (dw0..dw3, db); their sums over B are the parameter gradients. */
+int hmx_conv_silu_fwd(const float* x, const float* w, const float* b, int64_t T, int64_t L, int64_t C, float* xc,
+                      void* stream);
+int hmx_conv_silu_bwd(const float* x, const float* w, const float* b, const float* dxc, int64_t B, int64_t L,
+                      int64_t C, float* dx, float* part, void* stream);
+
+/* Selective scan of all heads (hydra3.py:107-123, 203-214) fused with the dt projection + softplus
+ * (:210) and the SiLU(z) gate (:273).  C = H * ED channels, ED a power of two >= 32, state N = 16,
+ * dt rank 16.  dbc (T, H, 48) = [dt_rank | B | C] rows of deltaBC_layer.  hs (T, C, 16), if not NULL,
+ * receives every state for the backward pass.  Backward writes dxc, dz, per-group partials of d(dbc)
+ * shaped (T, H, hmx_scan_groups_per_head(ED), 48) (sum with hmx_sum_groups_f32) and per-sequence
+ * parameter partials par_part (B, C, 34) = [dA_log(16) | dW_dt(16) | db_dt | dD]. */
+int hmx_scan_fwd(const float* xc, const float* z, const float* dbc, const float* Wdt, const float* bdt,
+                 const float* A_log, const float* D, int64_t B, int64_t L, int64_t C, int64_t ED, int64_t H, float* yg,
+                 float* hs, void* stream);
+int64_t hmx_scan_groups_per_head(int64_t ED);
+int hmx_scan_bwd(const float* xc, const float* z, const float* dbc, const float* Wdt, const float* bdt,
+                 const float* A_log, const float* D, const float* hs, const float* dyg, int64_t B, int64_t L, int64_t C,
+                 int64_t ED, int64_t H, float* dxc, float* dz, float* ddbc_part, float* par_part, void* stream);
+int hmx_sum_groups_f32(const float* part, int64_t rows, int64_t groups, int64_t width, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Benchmark support (no counterpart in the reference).  When enabled, entry points bracket
  * their dominant kernel with HIP events on the caller's stream; hmx_profile_collect blocks
  * until the events of spans tagged `tag` have completed, returns their summed duration and
- * count, and forgets them.  Tags: "topk_coarse_bf16", "topk_coarse_f32".
+ * count, and forgets them.  Tags: "topk_coarse_bf16", "topk_coarse_f32", "gather_rows", "scatter_segment_sum".
  * ------------------------------------------------------------------------------- */
 int hmx_profile_enable(int on);
 int hmx_profile_collect(const char* tag, double* total_ms, int64_t* launches);

@@ -1,0 +1,265 @@
+"""GPU parity of the encoder kernels (through the drop-in modules, i.e. through the C ABI) against
+(1) golden vectors captured from the reference's own code and (2) the CPU oracle at benchmark-like sizes.
+
+Tolerance.  Dense projections run on bf16 MFMA with fp32 accumulation, everything else is fp32.
+Default mode (split-bf16: operands carried as hi + lo bf16 pairs, 16 significant bits) is asserted as
+    max |err| <= 2e-3 * max |ref| + 1e-4     and     rms(err) <= 1e-3 * rms(ref) + 1e-5
+for forward values, 2x that for input gradients and 4x / 6.5x for parameter gradients.
+Fast mode (one bf16 MFMA per product, operands rounded to 8 significant bits) is asserted at 3e-2 / 1e-2 on the
+end-to-end encoder output (test_fast_bf16_mode_tolerance); its parameter gradients are bf16-noisy (up to 13 % rms
+on the deltaBC projection at L = 100) and are not asserted."""
+import pytest
+import torch
+
+import _golden as G
+from generative_recommenders_amd import enc_ops as E
+from generative_recommenders_amd import hydra as H
+from oracle import hydra_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(got, ref, mx=2e-3, rms=1e-3, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref)
+    m_ok = err.abs().max().item() <= mx * ref.abs().max().item() + 1e-4
+    r_ok = err.square().mean().sqrt().item() <= rms * ref.square().mean().sqrt().item() + 1e-5
+    assert m_ok and r_ok, (f"{what}: max err {err.abs().max().item():.3e} (ref max {ref.abs().max().item():.3e}), "
+                           f"rms err {err.square().mean().sqrt().item():.3e} (ref rms {ref.square().mean().sqrt().item():.3e})")
+
+
+def run_module_case(store, prefix, module, n_in, grad_inputs=(0,), mx=2e-3, rms=1e-3):
+    module.load_state_dict(G.params(store, prefix), strict=True)
+    module.to(DEV).eval()
+    ins = []
+    for i in range(n_in):
+        v = G.t(store, f"{prefix}/in{i}").to(DEV)
+        ins.append(v.requires_grad_() if i in grad_inputs else v)
+    y = module(*ins)
+    close(y, G.t(store, prefix + "/y"), mx, rms, prefix + " y")
+    y.backward(G.t(store, prefix + "/G").to(DEV))
+    for i in grad_inputs:
+        close(ins[i].grad, G.t(store, f"{prefix}/din{i}"), 2 * mx, 2.5 * rms, f"{prefix} din{i}")
+    gold = G.grads(store, prefix)
+    got = {k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+    assert set(gold) == set(got), set(gold) ^ set(got)
+    for k in gold:
+        close(got[k], gold[k], 4 * mx, 6.5 * rms, f"{prefix} grad {k}")
+
+
+def test_rmsnorm_fp32_exact_path():
+    s, p = G.load("g3_rmsnorm"), "G3_rmsnorm"
+    m = H.RMSNorm(16).to(DEV)
+    m.scale.data = G.t(s, p + "/scale").to(DEV)
+    x = G.t(s, p + "/x").to(DEV).requires_grad_()
+    y = m(x)
+    y.backward(G.t(s, p + "/G").to(DEV))
+    G.assert_close(y.detach().cpu(), G.t(s, p + "/y"), 1e-5, 1e-6)
+    G.assert_close(x.grad.cpu(), G.t(s, p + "/dx"), 1e-4, 1e-5)
+    G.assert_close(m.scale.grad.cpu(), G.t(s, p + "/dscale"), 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("T,N,K", [(70, 48, 128), (33, 64, 64), (1000, 256, 32), (5, 16, 8), (257, 100, 60), (64, 32, 256)])
+def test_linear_kernel_vs_fp32(T, N, K):
+    g = torch.Generator().manual_seed(T + N + K)
+    x = torch.randn(T, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    r1 = torch.randn(T, N, generator=g)
+    om = (torch.rand(T, generator=g) > 0.3).float()
+    xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    r1d = r1.to(DEV).requires_grad_()
+    y = E.linear(xd, wd, bd, r1=r1d, c1=2.0, out_mask=om.to(DEV))
+    xr, wr, br, rr = (t.clone().requires_grad_() for t in (x, w, b, r1))
+    yr = (xr @ wr.t() + br + 2.0 * rr) * om[:, None]
+    close(y, yr, 1e-4, 1e-4, "linear y")
+    gy = torch.randn(T, N, generator=g)
+    y.backward(gy.to(DEV))
+    yr.backward(gy)
+    close(xd.grad, xr.grad, 1e-4, 1e-4, "dx")
+    close(wd.grad, wr.grad, 1e-3, 1e-3, "dw (fp32 MFMA)")
+    close(bd.grad, br.grad, 1e-4, 1e-4, "db")
+    close(r1d.grad, rr.grad, 1e-6, 1e-6, "dr1")
+
+
+def test_selective_scan_kernel_vs_reference_golden():
+    """SSM module (deltaBC projection + dt projection + softplus + scan) against the oracle on the same weights."""
+    torch.manual_seed(0)
+    ref = O.SSM(64, 16, 64, 16)
+    for p in ref.parameters():
+        p.data = torch.randn_like(p) * 0.3
+    mine = H.SSM(64, 16, 64, 16)
+    mine.load_state_dict(ref.state_dict())
+    mine.to(DEV)
+    x = torch.randn(3, 37, 64)
+    xr = x.clone().requires_grad_()
+    xd = x.to(DEV).requires_grad_()
+    yr, yd = ref(xr), mine(xd)
+    close(yd, yr, 2e-3, 1e-3, "ssm y")
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    yd.backward(g.to(DEV))
+    close(xd.grad, xr.grad, 4e-3, 2e-3, "ssm dx")
+    for (k, pr), (_, pd) in zip(ref.named_parameters(), mine.named_parameters()):
+        close(pd.grad, pr.grad, 8e-3, 6.5e-3, "ssm grad " + k)
+
+
+@pytest.mark.parametrize("hd", [8, 32])
+def test_mamba_block_golden(hd):
+    run_module_case(G.load("g4_mamba"), f"G4_mamba_hd{hd}", H.MambaBlock(hd, 16, 4 * hd, 16), 1)
+
+
+def test_multi_head_mamba_golden():
+    m = H.MultiHeadMamba(16, 16, 64, 16, H.make_args(16, 12))
+    run_module_case(G.load("g5_mhm"), "G5_mhm", m, 3, grad_inputs=(0, 1))
+
+
+@pytest.mark.parametrize("name,cls", [("first", H.HydraBlockFirst), ("regular", H.HydraBlock)])
+def test_hydra_blocks_golden(name, cls):
+    run_module_case(G.load("g6_blocks"), f"G6_block_{name}", cls(16, 16, 64, 16, H.make_args(16, 14)), 2)
+
+
+@pytest.mark.parametrize("L", [2, 7, 10, 25, 26, 40])
+def test_multiscale_golden(L):
+    m = H.MultiScaleUserEncoder(16, 16, 64, 16, H.make_args(16, L))
+    run_module_case(G.load("g7_multiscale"), f"G7_multiscale_L{L}", m, 2)
+
+
+def _model_from(store, prefix, dropout=0.2):
+    U, I, d, L = (int(store[f"{prefix}/{k}"]) for k in "UIdL")
+    args = H.make_args(d, L, dropout=dropout)
+    m = H.Hydra(U, I, {}, H.IDS_ONLY_FEAT_TYPES, args, H.SharedEmbeddingModule(U, I, {}, H.IDS_ONLY_FEAT_TYPES, args))
+    m.load_state_dict(G.params(store, prefix), strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("d", [16, 64])
+def test_log2feats_golden(d):
+    s, p = G.load("g8_log2feats"), f"G8_log2feats_d{d}"
+    m = _model_from(s, p).eval()
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    with torch.no_grad():
+        out = m.log2feats(b["seq"], feat, b["tok"], b["ts"], b["act"], b["dwell"])
+        ue = m.get_user_embedding(b["seq"], feat, b["tok"], b["ts"], b["act"], b["dwell"])
+    close(out, G.t(s, p + "/out"), 2e-3, 1e-3, "log2feats")
+    close(ue, G.t(s, p + "/user_emb"), 2e-3, 1e-3, "user_emb")
+    assert torch.all(out[b["seq"] == 0] == 0)
+
+
+def test_input_assembly_is_fp32_tight():
+    """Gathers, position / time-bin / action / dwell lookups and the mask are exact; only hydra_projection rounds."""
+    s, p = G.load("g8_log2feats"), "G8_log2feats_d16"
+    m = _model_from(s, p).eval()
+    ref = O.Hydra(int(s[p + "/U"]), int(s[p + "/I"]), {}, O.IDS_ONLY_FEAT_TYPES, O.make_args(16, int(s[p + "/L"])))
+    ref.load_state_dict(G.params(s, p), strict=True)
+    b = {k: G.t(s, f"{p}/{k}") for k in ("seq", "tok", "ts", "act", "dwell")}
+    want, pm = ref.assemble_inputs(b["seq"], None, b["tok"], b["ts"], b["act"], b["dwell"])
+    got, pm2 = m.assemble_inputs(*(b[k].to(DEV) for k in ("seq", "tok", "ts", "act", "dwell")))
+    assert torch.equal(pm2.cpu(), pm)
+    close(got, want, 1e-4, 1e-4, "assembled inputs")
+    mask, pos, tb = E.seq_index(b["seq"].to(DEV), b["ts"].to(DEV), 512)
+    assert torch.equal(tb.cpu().view_as(b["seq"]), O.time_bins_from_timestamps(b["seq"], b["ts"], 512))
+
+
+def test_train_step_against_reference_golden():
+    """Loss and gradients of Hydra.forward.  The in-batch negatives are sampled by the GPU RNG, so the loss is
+    compared on the 'small' case whose sampling is exhaustive (all in-batch keys + random global padding is the
+    only RNG use); tolerance is loose there and tight on the RNG-free structure: the set of touched table rows."""
+    s, p = G.load("g10_train"), "G10_train_small"
+    m = _model_from(s, p, dropout=0.0).train()
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    torch.manual_seed(0)
+    loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, feat, feat, feat, b["ts"], b["act"], b["dwell"])
+    loss.backward()
+    ref_loss = float(s[p + "/loss"])
+    assert abs(loss.item() - ref_loss) < 0.15 * abs(ref_loss) + 0.05
+    gu = m.shared_embeddings.user_emb.weight.grad
+    rows = G.t(s, f"{p}/grad_rows/shared_embeddings.user_emb.weight")
+    assert torch.equal(gu.abs().sum(1).nonzero().flatten().cpu(), rows)
+    assert float(m.shared_embeddings.item_emb.weight.grad[0].abs().sum()) == 0.0
+
+
+def test_log2feats_and_grads_vs_oracle_benchmark_shape():
+    """d = 64, L = 100 (the benchmark model), B = 6 with ragged left padding; eval mode."""
+    from generative_recommenders_amd import synth
+    U, I, d, L, B = 500, 3000, 64, 100, 6
+    ref = O.build_model(U, I, d=d, L=L, seed=11).eval()
+    m = H.Hydra(U, I, {}, H.IDS_ONLY_FEAT_TYPES, H.make_args(d, L),
+                H.SharedEmbeddingModule(U, I, {}, H.IDS_ONLY_FEAT_TYPES, H.make_args(d, L)))
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m.to(DEV).eval()
+    bt = synth.train_batch(B, L, U, I, "cpu", seed=12, pad_frac=0.5)
+    feat = [[] for _ in range(B)]
+    want = ref.log2feats(bt["seq"], feat, bt["tok"], bt["ts"], bt["act"], bt["dwell"])
+    got = m.log2feats(*(bt[k].to(DEV) if k != "feat" else feat for k in ("seq", "feat", "tok", "ts", "act", "dwell")))
+    close(got, want, 2e-3, 1e-3, "log2feats d64 L100")
+    g = torch.randn_like(want)
+    want.backward(g)
+    got.backward(g.to(DEV))
+    pr, pd = dict(ref.named_parameters()), dict(m.named_parameters())
+    checked = 0
+    for k, q in pr.items():
+        if q.grad is None:
+            assert pd[k].grad is None or float(pd[k].grad.abs().sum()) == 0.0, k
+            continue
+        close(pd[k].grad, q.grad, 8e-3, 6.5e-3, "grad " + k)
+        checked += 1
+    assert checked > 100
+
+
+@pytest.mark.parametrize("B,L,ED,H", [(2, 37, 32, 2), (3, 100, 128, 2), (2, 130, 64, 1), (1, 5, 256, 2)])
+def test_scan_kernel_alone_is_fp32_tight(B, L, ED, H):
+    """The fused scan (dt projection + softplus + recurrence + D skip + SiLU(z) gate), forward and backward, against
+    the oracle's selective_scan on identical fp32 inputs: no bf16 anywhere, so agreement is at fp32 level."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    C, T = ED * H, B * L
+    xc = torch.randn(T, C, generator=g)
+    z = torch.randn(T, C, generator=g)
+    dbc = torch.randn(T, H * 48, generator=g) * 0.5
+    Wdt = torch.randn(C, 16, generator=g) * 0.3
+    bdt = torch.randn(C, generator=g) * 0.3
+    A_log = torch.randn(C, 16, generator=g) * 0.5
+    D = torch.randn(C, generator=g)
+    leaves_cpu = [t.clone().requires_grad_() for t in (xc, z, dbc, Wdt, bdt, A_log, D)]
+    leaves_gpu = [t.to(DEV).requires_grad_() for t in (xc, z, dbc, Wdt, bdt, A_log, D)]
+    # oracle, head by head
+    x_, z_, dbc_, W_, b_, Al_, D_ = leaves_cpu
+    outs = []
+    for h in range(H):
+        sl = slice(h * ED, (h + 1) * ED)
+        d3 = dbc_.view(B, L, H, 48)[:, :, h]
+        delta = F.softplus(F.linear(d3[..., :16], W_[sl], b_[sl]))
+        y = O.selective_scan(x_.view(B, L, C)[..., sl], delta, -torch.exp(Al_[sl]), d3[..., 16:32], d3[..., 32:], D_[sl])
+        outs.append(y * F.silu(z_.view(B, L, C)[..., sl]))
+    want = torch.cat(outs, dim=-1).reshape(T, C)
+    got = E.selective_scan_gated(*leaves_gpu, L, ED, H)
+    G.assert_close(got.detach().cpu(), want.detach(), 2e-4, 2e-4, "scan y")
+    gy = torch.randn(T, C, generator=g)
+    want.backward(gy)
+    got.backward(gy.to(DEV))
+    for name, a, b in zip(("xc", "z", "dbc", "Wdt", "bdt", "A_log", "D"), leaves_gpu, leaves_cpu):
+        scale = b.grad.abs().max().item()
+        G.assert_close(a.grad.cpu(), b.grad, 1e-3, 1e-4 * max(scale, 1.0), "scan d" + name)
+
+
+def test_fast_bf16_mode_tolerance():
+    """Single-bf16 projections (hmx.set_linear_precision(False)): end-to-end encoder output within 3e-2 / 1e-2."""
+    from generative_recommenders_amd import hmx
+    s, p = G.load("g8_log2feats"), "G8_log2feats_d64"
+    m = _model_from(s, p).eval()
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    hmx.set_linear_precision(False)
+    try:
+        with torch.no_grad():
+            out = m.log2feats(b["seq"], feat, b["tok"], b["ts"], b["act"], b["dwell"])
+    finally:
+        hmx.set_linear_precision(True)
+    close(out, G.t(s, p + "/out"), 3e-2, 1e-2, "log2feats fast mode")
+    err = (out.cpu() - G.t(s, p + "/out")).abs().max().item()
+    assert err > 1e-5          # it really was the rounded path
