@@ -737,7 +737,7 @@ extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64
     return HMX_OK;
 }
 
-static int64_t wgrad_splits(int64_t T) { return std::max<int64_t>(1, std::min<int64_t>(256, hmx_ceil_div(T, 256))); }
+static int64_t wgrad_splits(int64_t T) { return std::max<int64_t>(1, std::min<int64_t>(64, hmx_ceil_div(T, 256))); }
 
 extern "C" size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K) {
     return (size_t)wgrad_splits(T) * N * (K + 1) * sizeof(float) + 256;

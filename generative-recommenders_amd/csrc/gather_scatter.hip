@@ -123,18 +123,27 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const int64_t* __rest
     }
 }
 
-// Step 3: one group of LPR lanes owns a chunk of kChunk consecutive sorted entries.  Every
-// distinct id whose FIRST sorted entry lies in the chunk is summed by that group, walking
-// its whole run in sorted (= original, the sort is stable) order, then added to the table
-// row once.  Runs are disjoint, so there is exactly one writer per row: no atomics.
+// Step 3 (pass 1): the sorted array is cut at every change of id AND at every multiple of kSuper
+// entries into "pieces"; one group of LPR lanes sums one piece sequentially in sorted (= original, the
+// sort is stable) order.  A group owns the pieces whose first entry lies in its chunk of kChunk entries.
+//   piece == whole run            -> added to the table row (exactly one writer per row)
+//   piece continues an older run  -> head_piece[super-block]   (it starts at the block's first entry)
+//   piece starts a run that goes on past the block end -> tail_piece[super-block]
+// Pass 2: the group of the block where such a run starts adds tail_piece[b] + head_piece[b+1] + ... in
+// block order and writes the row.  The association order depends only on positions in the sorted array,
+// never on timing, so the result is bitwise reproducible; no float atomics; the sequential depth is
+// bounded by kSuper whatever the id skew.
 constexpr int kChunk = 8;
+constexpr int kSuper = 512;
 
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void segment_sum_kernel(const float* __restrict__ grad_rows,
                                                              const uint32_t* __restrict__ skeys,
                                                              const uint32_t* __restrict__ svals, int64_t n, int cpr,
                                                              int lpr_log2, uint32_t sentinel,
-                                                             float* __restrict__ grad_table) {
+                                                             float* __restrict__ grad_table,
+                                                             float* __restrict__ head_piece,
+                                                             float* __restrict__ tail_piece) {
     using V = typename VecT<VEC>::type;
     const int lpr = 1 << lpr_log2;
     const int lane_c = threadIdx.x & (lpr - 1);
@@ -145,13 +154,18 @@ __global__ __launch_bounds__(kBlock) void segment_sum_kernel(const float* __rest
          g += (int64_t)gridDim.x * groups_per_block) {
         const int64_t j0 = g * kChunk;
         const int64_t j1 = (j0 + kChunk < n) ? j0 + kChunk : n;
+        const int64_t sb = j0 / kSuper;                       // kSuper is a multiple of kChunk
+        const int64_t blk_end = ((sb + 1) * kSuper < n) ? (sb + 1) * kSuper : n;
         uint32_t prev = (j0 == 0) ? sentinel : skeys[j0 - 1];
         for (int64_t j = j0; j < j1; ++j) {
             const uint32_t key = skeys[j];
             if (key == sentinel) break;          // sentinels sort last: nothing further in this chunk
-            const bool head = (j == 0) || key != prev;
+            const bool starts_true = (j == 0) || key != prev;
+            const bool head = starts_true || (j % kSuper == 0);
             prev = key;
             if (!head) continue;
+            // extent of the piece: [j, e_end)
+            int64_t e_end = j;
             for (int c = lane_c; c < cpr; c += lpr) {
                 V acc = vzero<VEC>();
                 int64_t e = j;
@@ -161,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void segment_sum_kernel(const float* __rest
                     bool run = true;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        run = run && (e + u < n) && (skeys[e + u] == key);
+                        run = run && (e + u < blk_end) && (skeys[e + u] == key);
                         m[u] = run;
                     }
 #pragma unroll
@@ -169,15 +183,72 @@ __global__ __launch_bounds__(kBlock) void segment_sum_kernel(const float* __rest
                         v[u] = m[u] ? rows[(int64_t)svals[e + u] * cpr + c] : vzero<VEC>();
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (m[u]) vadd(acc, v[u]);
+                        if (m[u]) {
+                            vadd(acc, v[u]);
+                            e_end = e + u + 1;
+                        }
                     if (!m[3]) break;
                     e += 4;
                 }
-                V* dst = reinterpret_cast<V*>(grad_table) + (int64_t)key * cpr + c;
-                V cur = *dst;
-                vadd(cur, acc);
-                *dst = cur;
+                {
+                    const bool ends_true = (e_end == n) || skeys[e_end] != key;
+                    V* dst;
+                    bool add;
+                    if (starts_true && ends_true) {
+                        dst = reinterpret_cast<V*>(grad_table) + (int64_t)key * cpr + c;
+                        add = true;
+                    } else if (!starts_true) {
+                        dst = reinterpret_cast<V*>(head_piece) + sb * cpr + c;
+                        add = false;
+                    } else {
+                        dst = reinterpret_cast<V*>(tail_piece) + sb * cpr + c;
+                        add = false;
+                    }
+                    if (add) {
+                        V cur = *dst;
+                        vadd(cur, acc);
+                        *dst = cur;
+                    } else {
+                        *dst = acc;
+                    }
+                }
             }
+        }
+    }
+}
+
+// Pass 2: one group per super-block b; acts only if a run starts inside b and continues past its end.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void segment_join_kernel(const uint32_t* __restrict__ skeys, int64_t n, int cpr,
+                                                              int lpr_log2, uint32_t sentinel,
+                                                              float* __restrict__ grad_table,
+                                                              const float* __restrict__ head_piece,
+                                                              const float* __restrict__ tail_piece) {
+    using V = typename VecT<VEC>::type;
+    const int lpr = 1 << lpr_log2;
+    const int lane_c = threadIdx.x & (lpr - 1);
+    const int groups_per_block = kBlock >> lpr_log2;
+    const int64_t n_sb = (n + kSuper - 1) / kSuper;
+    for (int64_t b = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> lpr_log2); b < n_sb;
+         b += (int64_t)gridDim.x * groups_per_block) {
+        const int64_t end = (b + 1) * kSuper;
+        if (end >= n) continue;                                   // last block: nothing continues
+        const uint32_t key = skeys[end - 1];
+        if (key == sentinel || skeys[end] != key) continue;       // no run crosses this boundary
+        if (skeys[b * kSuper] == key && b > 0 && skeys[b * kSuper - 1] == key) continue;  // run started earlier
+        for (int c = lane_c; c < cpr; c += lpr) {
+            V acc = reinterpret_cast<const V*>(tail_piece)[b * cpr + c];
+            int64_t cb = b + 1;
+            while (true) {
+                vadd(acc, reinterpret_cast<const V*>(head_piece)[cb * cpr + c]);
+                const int64_t cend = (cb + 1) * kSuper;
+                if (cend < n && skeys[cend - 1] == key && skeys[cend] == key) ++cb;
+                else break;
+            }
+            V* dst = reinterpret_cast<V*>(grad_table) + (int64_t)key * cpr + c;
+            V cur = *dst;
+            vadd(cur, acc);
+            *dst = cur;
         }
     }
 }
@@ -216,10 +287,14 @@ extern "C" int hmx_gather_routed_f32(const float* item_table, int64_t item_rows,
                                (hipStream_t)stream);
 }
 
-extern "C" size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows) {
-    if (n <= 0 || n_rows <= 0) return 256;
+static size_t piece_bytes(int64_t n, int64_t d) {
+    return hmx_align_up((size_t)hmx_ceil_div(n, kSuper) * (size_t)d * sizeof(float), 256);
+}
+
+extern "C" size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows, int64_t d) {
+    if (n <= 0 || n_rows <= 0 || d <= 0) return 256;
     const size_t arr = hmx_align_up((size_t)n * sizeof(uint32_t), 256);
-    return 4 * arr + hmx_align_up(rocprim_sort_temp_bytes(n, sort_bits(n_rows)), 256) + 256;
+    return 4 * arr + 2 * piece_bytes(n, d) + hmx_align_up(rocprim_sort_temp_bytes(n, sort_bits(n_rows)), 256) + 256;
 }
 
 extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
@@ -233,12 +308,14 @@ extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* i
     const int bits = sort_bits(n_rows);
     size_t temp_bytes = rocprim_sort_temp_bytes(n, bits);
     const size_t arr = hmx_align_up((size_t)n * sizeof(uint32_t), 256);
-    if (workspace_bytes < 4 * arr + hmx_align_up(temp_bytes, 256)) return HMX_EWORKSPACE;
+    if (workspace_bytes < 4 * arr + 2 * piece_bytes(n, d) + hmx_align_up(temp_bytes, 256)) return HMX_EWORKSPACE;
     HmxCarver ws(workspace);
     uint32_t* keys = ws.take<uint32_t>(n);
     uint32_t* vals = ws.take<uint32_t>(n);
     uint32_t* skeys = ws.take<uint32_t>(n);
     uint32_t* svals = ws.take<uint32_t>(n);
+    float* head_piece = ws.take<float>(piece_bytes(n, d) / sizeof(float));
+    float* tail_piece = ws.take<float>(piece_bytes(n, d) / sizeof(float));
     void* temp = ws.take<char>(temp_bytes);
     const uint32_t sentinel = (uint32_t)n_rows;
 
@@ -256,12 +333,19 @@ extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* i
     const int64_t groups = hmx_ceil_div(n, kChunk);
     const int grid3 = (int)std::min<int64_t>(hmx_ceil_div(groups, kBlock >> l2), (int64_t)kMaxGrid * 4);
     void* span = hmx_profile_begin("scatter_segment_sum", s);
-    if (vec)
+    const int64_t n_sb = hmx_ceil_div(n, kSuper);
+    const int grid4 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid);
+    if (vec) {
         hipLaunchKernelGGL(segment_sum_kernel<4>, dim3(grid3), dim3(kBlock), 0, s, grad_rows, skeys, svals, n, (int)cpr,
-                           l2, sentinel, grad_table);
-    else
+                           l2, sentinel, grad_table, head_piece, tail_piece);
+        hipLaunchKernelGGL(segment_join_kernel<4>, dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2, sentinel,
+                           grad_table, head_piece, tail_piece);
+    } else {
         hipLaunchKernelGGL(segment_sum_kernel<1>, dim3(grid3), dim3(kBlock), 0, s, grad_rows, skeys, svals, n, (int)cpr,
-                           l2, sentinel, grad_table);
+                           l2, sentinel, grad_table, head_piece, tail_piece);
+        hipLaunchKernelGGL(segment_join_kernel<1>, dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2, sentinel,
+                           grad_table, head_piece, tail_piece);
+    }
     hmx_profile_end(span, s);
     HMX_CHECK_LAUNCH();
     return HMX_OK;

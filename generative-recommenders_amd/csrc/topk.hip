@@ -285,7 +285,9 @@ struct RescoreParams {
     const float* meta_thr;
     int k;
     int64_t id_offset;
-    const float* max_row_norm;  // null => exact coarse pass (no proof needed)
+    const float* max_row_norm;  // null => exact coarse pass (error bound 0)
+    const int64_t* exclude;     // (n_q, n_excl) global ids removed here (null: none, or already removed upstream)
+    int n_excl;
     int64_t* out_ids;           // (n_q, k)
     float* out_scores;
     int32_t* uncertain;         // (n_q) or null
@@ -327,8 +329,15 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
                 const float* tv = p.t_f32 + row * p.d;
                 float a = 0.f;
                 for (int k = 0; k < p.d; ++k) a = __builtin_fmaf(qv[k], tv[k], a);
-                sc[i] = a;
-                id[i] = row + p.id_offset;
+                bool keep = true;
+                if (p.exclude != nullptr) {
+                    const int64_t* ex = p.exclude + q * p.n_excl;
+                    for (int x = 0; x < p.n_excl; ++x) keep = keep && (ex[x] != row + p.id_offset);
+                }
+                if (keep) {
+                    sc[i] = a;
+                    id[i] = row + p.id_offset;
+                }
             }
         }
     }
@@ -390,11 +399,14 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
     }
     if (p.uncertain != nullptr && q_ok && t == 0) {
         int flag = 0;
-        if (p.max_row_norm != nullptr && tmax > kNegInf) {
-            float n2 = 0.f;
-            for (int k = 0; k < p.d; ++k) n2 = __builtin_fmaf(qv[k], qv[k], n2);
-            // |bf16 coarse score - exact score| <= (2^-8 + small) * |q| * max|t|   (two bf16 roundings per product)
-            const float eps = 0.00398f * sqrtf(n2) * p.max_row_norm[0];
+        if (tmax > kNegInf) {
+            float eps = 0.f;
+            if (p.max_row_norm != nullptr) {
+                float n2 = 0.f;
+                for (int k = 0; k < p.d; ++k) n2 = __builtin_fmaf(qv[k], qv[k], n2);
+                // |bf16 coarse score - exact score| <= (2^-8 + small) * |q| * max|t|  (two bf16 roundings per product)
+                eps = 0.00398f * sqrtf(n2) * p.max_row_norm[0];
+            }
             flag = !(kth > tmax + eps);
         }
         p.uncertain[q] = flag;
@@ -405,23 +417,47 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
 __global__ __launch_bounds__(256) void to_bf16_padded_kernel(const float* __restrict__ src, int64_t rows, int d,
                                                              int64_t rows_pad, int dpad, uint16_t* __restrict__ dst,
                                                              unsigned* __restrict__ max_norm_bits) {
-    // one 16-lane group per output row chunk; row norm reduced inside the group
-    const int lpr = 16;
-    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
-    const int c = threadIdx.x % lpr;
-    float n2 = 0.f;
-    if (row < rows_pad) {
-        for (int k = c; k < dpad; k += lpr) {
-            const float v = (row < rows && k < d) ? src[row * d + k] : 0.f;
-            n2 += v * v;
-            dst[row * dpad + k] = hmx_f32_to_bf16(v);
+    // one group of 16 lanes per output row, 4 consecutive elements per lane and step (dpad is a multiple of 16);
+    // the row norm is reduced inside the group and the block's largest norm goes out through one atomic
+    __shared__ float wave_max[4];
+    const int c = threadIdx.x & 15;
+    const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    float best = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < (rows_pad + 15) / 16 * 16;
+         row += (int64_t)gridDim.x * 16) {
+        float n2 = 0.f;
+        if (row < rows_pad) {
+            for (int k = 4 * c; k < dpad; k += 64) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows) {
+                    if (vec && k + 4 <= d) {
+                        v = *reinterpret_cast<const float4*>(src + row * d + k);
+                    } else {
+                        if (k < d) v.x = src[row * d + k];
+                        if (k + 1 < d) v.y = src[row * d + k + 1];
+                        if (k + 2 < d) v.z = src[row * d + k + 2];
+                        if (k + 3 < d) v.w = src[row * d + k + 3];
+                    }
+                }
+                n2 += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                uint2 o;
+                o.x = (uint32_t)hmx_f32_to_bf16(v.x) | ((uint32_t)hmx_f32_to_bf16(v.y) << 16);
+                o.y = (uint32_t)hmx_f32_to_bf16(v.z) | ((uint32_t)hmx_f32_to_bf16(v.w) << 16);
+                *reinterpret_cast<uint2*>(dst + row * dpad + k) = o;
+            }
         }
+        for (int off = 8; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
+        best = fmaxf(best, n2);
     }
     if (max_norm_bits != nullptr) {
-        for (int off = 8; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
-        for (int off = 32; off >= 16; off >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, off));
+        for (int off = 32; off >= 16; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = best;
+        __syncthreads();
         // slightly inflated so that the rounding of this reduction can never under-state a norm
-        if ((threadIdx.x & 63) == 0) atomicMax(max_norm_bits, __float_as_uint(sqrtf(n2) * 1.0001f));
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+            atomicMax(max_norm_bits, __float_as_uint(sqrtf(m) * 1.0001f));
+        }
     }
 }
 
@@ -523,10 +559,11 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
     return true;
 }
 
+// The bf16 coarse pass never looks at the exclusion lists: excluded ids are removed when the shortlist is
+// re-scored, and the completeness proof there covers what they displaced.
 template <int NB, int KS, int KP>
-void launch_bf16(const CoarseParams& p, int waves, bool excl, hipStream_t s) {
-    if (excl) hipLaunchKernelGGL((coarse_bf16_kernel<NB, KS, KP, true>), dim3(waves), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((coarse_bf16_kernel<NB, KS, KP, false>), dim3(waves), dim3(64), 0, s, p);
+void launch_bf16(const CoarseParams& p, int waves, bool, hipStream_t s) {
+    hipLaunchKernelGGL((coarse_bf16_kernel<NB, KS, KP, false>), dim3(waves), dim3(64), 0, s, p);
 }
 template <int NB, int KS>
 void launch_bf16_kp(const CoarseParams& p, int waves, int KP, bool excl, hipStream_t s) {
@@ -600,7 +637,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
         void* span = nullptr;
         if (bf16) {
             const int64_t rows_pad = (int64_t)n_qtiles * qpw;
-            hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)hmx_ceil_div(rows_pad * 16, 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)std::min<int64_t>(hmx_ceil_div(rows_pad, 16), 8192)), dim3(256), 0, s,
                                queries + q0 * d, nq, (int)d, rows_pad, pl.dpad, q_bf16, (unsigned*)nullptr);
             span = hmx_profile_begin("topk_coarse_bf16", s);
             if (pl.NB == 4) launch_bf16_ks<4>(p, waves, pl.KS, pl.KP, excl, s);
@@ -633,6 +670,9 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
         r.k = (int)k;
         r.id_offset = id_offset;
         r.max_row_norm = bf16 ? max_row_norm : nullptr;
+        // bf16 pass: exclusions are applied here.  fp32 pass: the coarse kernel already skipped them.
+        r.exclude = (bf16 && excl) ? exclude + q0 * n_excl : nullptr;
+        r.n_excl = (int)n_excl;
         r.out_ids = out_ids + q0 * k;
         r.out_scores = out_scores + q0 * k;
         r.uncertain = uncertain ? uncertain + q0 : nullptr;
@@ -650,7 +690,7 @@ extern "C" int hmx_table_prepare_bf16(const float* table, int64_t n_rows, int64_
     if (!table || !table_bf16 || !max_row_norm || n_rows <= 0 || d <= 0 || d > 128) return HMX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(max_row_norm, 0, sizeof(float), s) != hipSuccess) return HMX_ELAUNCH;
-    hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)hmx_ceil_div(n_rows * 16, 256)), dim3(256), 0, s, table,
+    hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)std::min<int64_t>(hmx_ceil_div(n_rows, 16), 8192)), dim3(256), 0, s, table,
                        n_rows, (int)d, n_rows, dpad_for(d), table_bf16, reinterpret_cast<unsigned*>(max_row_norm));
     HMX_CHECK_LAUNCH();
     return HMX_OK;

@@ -54,7 +54,7 @@ def scatter_add_rows(grad_rows, ids, n_rows, padding_idx=-1, token_type=None, wa
     if out is None:
         out = torch.zeros(n_rows, d, dtype=torch.float32, device=g.device)
     L = hmx.lib()
-    ws = workspace(L.hmx_scatter_add_rows_workspace_bytes(n, n_rows), g.device)
+    ws = workspace(L.hmx_scatter_add_rows_workspace_bytes(n, n_rows, d), g.device)
     hmx.check(L.hmx_scatter_add_rows_f32(hmx.ptr(g), hmx.ptr(ids), hmx.ptr(tt), want_type, n, d, hmx.ptr(out), n_rows,
                                          padding_idx, hmx.ptr(ws), ws.numel(), hmx.current_stream()),
               "hmx_scatter_add_rows_f32")

@@ -56,11 +56,13 @@ int hmx_gather_routed_f32(const float* item_table, int64_t item_rows, const floa
  *   ids[i] in range, and (token_type == NULL or token_type[i] == want_type).
  * Replaces ATen embedding_dense_backward / index_put_(accumulate=True) reached from
  * main.py:708 through embedding.py:445,450,454 and hydra3.py:917.
- * Deterministic: contributions to one row are summed in increasing i (a stable sort by id
- * followed by one sequential segment sum per distinct id; no float atomics).
+ * Deterministic, no float atomics: the (id, i) pairs are sorted stably by id; the sorted array is cut
+ * at every change of id and at every multiple of 512 entries; each piece is summed in increasing i from
+ * zero, the pieces of one id are added in order, and the total is added to the row once.  (For ids with
+ * at most 512 occurrences not straddling a cut this is the plain sum in increasing i.)
  * grad_table is NOT cleared here (the caller zero-fills or accumulates).
  * ------------------------------------------------------------------------------- */
-size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows);
+size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows, int64_t d);
 int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
                              int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
                              int64_t padding_idx, void* workspace, size_t workspace_bytes, void* stream);

@@ -38,25 +38,52 @@ void orc_gather_routed_f32(const float* item_table, int64_t item_rows, const flo
 }
 
 /* Backward of the gathers (ATen embedding_dense_backward / index_put_ accumulate, reached from
- * main.py:708): per destination row the contributions are summed from zero in increasing i,
- * then the sum is added to the row once. */
+ * main.py:708).  Summation order (the contract of the HIP kernel): contributing entries are ordered by
+ * (id, i); that ordered list is cut at every change of id and at every multiple of 512 positions; each
+ * piece is summed from zero in order, the pieces of one id are added in order, the total is added to the
+ * row once.  For an id with few occurrences this is simply the sum in increasing i. */
+#define ORC_SUPER 512
 void orc_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
                               int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
                               int64_t padding_idx) {
-    float* acc = (float*)calloc((size_t)(n_rows * d), sizeof(float));
-    unsigned char* touched = (unsigned char*)calloc((size_t)n_rows, 1);
+    int64_t* start = (int64_t*)calloc((size_t)n_rows + 1, sizeof(int64_t));
+    int64_t n_valid = 0;
     for (int64_t i = 0; i < n; ++i) {
         int64_t id = ids[i];
         if (id < 0 || id >= n_rows || id == padding_idx) continue;
         if (token_type && token_type[i] != want_type) continue;
-        touched[id] = 1;
-        for (int64_t c = 0; c < d; ++c) acc[id * d + c] += grad_rows[i * d + c];
+        start[id + 1]++;
+        n_valid++;
     }
-    for (int64_t r = 0; r < n_rows; ++r)
-        if (touched[r])
-            for (int64_t c = 0; c < d; ++c) grad_table[r * d + c] += acc[r * d + c];
-    free(acc);
-    free(touched);
+    for (int64_t r = 0; r < n_rows; ++r) start[r + 1] += start[r];
+    int64_t* order = (int64_t*)malloc((size_t)(n_valid > 0 ? n_valid : 1) * sizeof(int64_t));
+    int64_t* fill = (int64_t*)calloc((size_t)n_rows, sizeof(int64_t));
+    for (int64_t i = 0; i < n; ++i) {                     /* stable counting sort by id */
+        int64_t id = ids[i];
+        if (id < 0 || id >= n_rows || id == padding_idx) continue;
+        if (token_type && token_type[i] != want_type) continue;
+        order[start[id] + fill[id]++] = i;
+    }
+    float* total = (float*)malloc((size_t)d * sizeof(float));
+    float* piece = (float*)malloc((size_t)d * sizeof(float));
+    for (int64_t r = 0; r < n_rows; ++r) {
+        int64_t s = start[r], e = start[r + 1];
+        if (s == e) continue;
+        int first = 1;
+        while (s < e) {
+            int64_t cut = (s / ORC_SUPER + 1) * ORC_SUPER;
+            int64_t pe = cut < e ? cut : e;
+            for (int64_t c = 0; c < d; ++c) piece[c] = 0.0f;
+            for (int64_t p = s; p < pe; ++p)
+                for (int64_t c = 0; c < d; ++c) piece[c] += grad_rows[order[p] * d + c];
+            if (first) memcpy(total, piece, (size_t)d * sizeof(float));
+            else for (int64_t c = 0; c < d; ++c) total[c] += piece[c];
+            first = 0;
+            s = pe;
+        }
+        for (int64_t c = 0; c < d; ++c) grad_table[r * d + c] += total[c];
+    }
+    free(start); free(order); free(fill); free(total); free(piece);
 }
 
 /* s(q, j) = fma chain over k = 0..d-1 in fp32, starting from 0. */

@@ -58,6 +58,19 @@ def test_scatter_add_bit_exact(rows, d, n, hot):
     assert not got[0].any()
 
 
+@pytest.mark.parametrize("n,distinct,d", [(200_000, 5, 64), (70_000, 1, 64), (5000, 3, 16), (1537, 2, 128), (513, 1, 64)])
+def test_scatter_add_extreme_skew_bit_exact(n, distinct, d):
+    """Runs of tens of thousands of equal ids (every user mining the same hard negatives): pieces of 512 entries
+    are summed in parallel and joined in order; the oracle follows the same association."""
+    g = torch.Generator().manual_seed(n)
+    ids = torch.randint(1, distinct + 1, (n,), generator=g) * 7
+    grad = torch.randn(n, d, generator=g)
+    got = ops.scatter_add_rows(grad.to(DEV), ids.to(DEV), 100, padding_idx=0).cpu().numpy()
+    want = C.scatter_add_rows(grad.numpy(), ids.numpy(), 100, padding_idx=0)
+    assert np.array_equal(got, want)
+    np.testing.assert_allclose(got[7], grad[ids == 7].double().sum(0).float().numpy(), rtol=1e-3, atol=1e-2)
+
+
 def test_scatter_add_is_deterministic_and_accumulates():
     g = torch.Generator().manual_seed(8)
     ids = torch.randint(0, 40, (30000,), generator=g).to(DEV)
