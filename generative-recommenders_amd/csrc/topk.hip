@@ -32,6 +32,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr float kNegInf = -INFINITY;
 constexpr int kRoom = 16;  // free slots guaranteed before a tile's epilogue (one lane sees 16 scores per tile)
 
+// Candidate slots per lane list.  128 for both shortlist sizes: with KP = 32 the list is compacted every
+// ~80 appends instead of every 16, which more than pays for sorting two entries per lane.
+constexpr int cap_for(int KP) { return KP <= 32 ? 128 : 2 * KP; }
+
 struct CoarseParams {
     const uint16_t* q_bf16;   // (n_q_pad, dpad) bf16   [bf16 pass]
     const uint16_t* t_bf16;   // (n_rows, dpad) bf16    [bf16 pass]
@@ -68,8 +72,8 @@ __device__ __forceinline__ void decode_wave(const CoarseParams& p, int& qtile, i
 // (score desc, arrival asc == row asc) and returns the new threshold.
 template <int KP>
 __device__ __forceinline__ void compact_list(uint2* buf, int n, int& new_cnt, float& new_thr, float old_thr) {
-    constexpr int CAP = 2 * KP, EPL = CAP / 64;
-    const int lane = threadIdx.x;
+    constexpr int CAP = cap_for(KP), EPL = CAP / 64;
+    const int lane = threadIdx.x & 63;
     float s[EPL];
     unsigned id[EPL];
     int rank[EPL];
@@ -109,21 +113,22 @@ __device__ __forceinline__ void compact_list(uint2* buf, int n, int& new_cnt, fl
     new_cnt = n < KP ? n : KP;
 }
 
-// Per-tile filter for one group of 32 queries.  acc: the 32x32 score tile; row0: local table
-// row of accumulator register 0 for this lane (tile base + 4 * (lane >> 5)).
+// Per-tile filter for one group of 32 queries.  acc: the 32x32 score tile; row0: local table row of accumulator
+// register 0 for this lane (tile base + 4 * (lane >> 5)).  Rows >= row_end (only possible in the last, partial
+// tile of an item range) must already hold -inf in acc.
 template <int KP, bool EXCL>
-__device__ __forceinline__ void tile_filter(const f32x16& acc, float& thr, int& cnt, uint2* group_buf, int64_t row0,
-                                            int64_t row_end, const CoarseParams& p, int64_t q_global) {
-    constexpr int CAP = 2 * KP;
+__device__ __forceinline__ void tile_filter(const f32x16& acc, float& thr, int& cnt, uint2* group_buf, int row0,
+                                            const CoarseParams& p, int64_t q_global) {
+    constexpr int CAP = cap_for(KP);
     float m = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
     if (__ballot(m > thr) == 0ull) return;  // wave-uniform fast path
-    uint2* mine = group_buf + (int64_t)threadIdx.x * CAP;
+    uint2* mine = group_buf + (threadIdx.x & 63) * CAP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-        bool pass = acc[r] > thr && row < row_end;
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        bool pass = acc[r] > thr;
         if (EXCL) {
             if (pass && q_global < p.n_q) {
                 const int64_t gid = row + p.id_offset;
@@ -144,17 +149,24 @@ __device__ __forceinline__ void tile_filter(const f32x16& acc, float& thr, int& 
         const float t_old = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr), o));
         int nc;
         float nt;
-        compact_list<KP>(group_buf + (int64_t)o * CAP, n, nc, nt, t_old);
-        if ((int)threadIdx.x == o) {
+        compact_list<KP>(group_buf + o * CAP, n, nc, nt, t_old);
+        if ((int)(threadIdx.x & 63) == o) {
             cnt = nc;
             thr = nt;
         }
     }
 }
 
+// -inf for the accumulator rows of a partial tile that lie beyond the item range
+__device__ __forceinline__ void mask_tail_rows(f32x16& acc, int row0, int row_end) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (row0 + (r & 3) + 8 * (r >> 2) >= row_end) acc[r] = kNegInf;
+}
+
 template <int KP>
 __device__ __forceinline__ void finish_group(float& thr, int& cnt, uint2* group_buf, int* meta_cnt, float* meta_thr) {
-    constexpr int CAP = 2 * KP;
+    constexpr int CAP = cap_for(KP);
     unsigned long long need = __ballot(cnt > KP);
     while (need) {
         const int o = __ffsll((long long)need) - 1;
@@ -164,20 +176,22 @@ __device__ __forceinline__ void finish_group(float& thr, int& cnt, uint2* group_
         int nc;
         float nt;
         compact_list<KP>(group_buf + (int64_t)o * CAP, n, nc, nt, t_old);
-        if ((int)threadIdx.x == o) {
+        if ((int)(threadIdx.x & 63) == o) {
             cnt = nc;
             thr = nt;
         }
     }
-    meta_cnt[threadIdx.x] = cnt;
-    meta_thr[threadIdx.x] = thr;
+    meta_cnt[threadIdx.x & 63] = cnt;
+    meta_thr[threadIdx.x & 63] = thr;
 }
 
-// launch bound of 2 waves per SIMD caps the kernel at 256 registers, which also makes the compiler keep the
-// MFMA accumulators in VGPRs (the filter reads them every tile; AGPR accumulators cost a v_accvgpr_read each).
-template <int NB, int KS, int KP, bool EXCL>
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 coarse pass.  (__launch_bounds__ of 2 waves per SIMD caps the kernel at 256 registers, which also makes the
+// compiler keep the MFMA accumulators in VGPRs: the filter reads them every tile and AGPR accumulators would cost
+// a v_accvgpr_read each.)
+template <int NB, int KS, int KP>
 __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
-    constexpr int CAP = 2 * KP;
+    constexpr int CAP = cap_for(KP);
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     int qtile, split;
     decode_wave(p, qtile, split);
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
     short8 bq[NB][KS];
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
-        const int64_t qrow = (int64_t)qtile * 32 * NB + 32 * g + j;  // q_bf16 is padded to a multiple of 32*NB rows
+        const int64_t qrow = (int64_t)qtile * 32 * NB + 32 * g + j;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             bq[g][ks] = *reinterpret_cast<const short8*>(p.q_bf16 + qrow * p.dpad + 16 * ks + 8 * h);
@@ -201,21 +215,20 @@ __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
         thr[g] = kNegInf;
         cnt[g] = 0;
     }
+    const int n_rows_here = (int)max(row_end - row_begin, (int64_t)0);
+    const int n_full = n_rows_here / 32;
+    const uint16_t* ap = p.t_bf16 + (row_begin + j) * p.dpad + 8 * h;
+    const int64_t tile_stride = 32 * (int64_t)p.dpad;
 
-    short8 a_cur[KS], a_nxt[KS];
-    {
-        const int64_t r = min(row_begin + j, p.n_rows - 1);
+    // Three fragment buffers, rotated by a loop unrolled three times: the loads of tile t+2 are issued before the
+    // MFMAs of tile t, so an L2 / HBM miss has two tile times to land.
+    short8 a0[KS], a1[KS], a2[KS];
+    auto load_tile = [&](short8(&dst)[KS], int t) {
+        const uint16_t* src = ap + (int64_t)t * tile_stride;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            a_cur[ks] = *reinterpret_cast<const short8*>(p.t_bf16 + r * p.dpad + 16 * ks + 8 * h);
-    }
-    for (int64_t i0 = row_begin; i0 < row_end; i0 += 32) {
-        {
-            const int64_t r = min(i0 + 32 + j, p.n_rows - 1);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                a_nxt[ks] = *reinterpret_cast<const short8*>(p.t_bf16 + r * p.dpad + 16 * ks + 8 * h);
-        }
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const short8*>(src + 16 * ks);
+    };
+    auto compute_tile = [&](const short8(&a)[KS], int t, bool partial) {
         f32x16 acc[NB];
 #pragma unroll
         for (int g = 0; g < NB; ++g) {
@@ -223,14 +236,40 @@ __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
             for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[ks], bq[g][ks], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bq[g][ks], acc[g], 0, 0, 0);
         }
+        const int row0 = (int)row_begin + 32 * t + 4 * h;
 #pragma unroll
-        for (int g = 0; g < NB; ++g)
-            tile_filter<KP, EXCL>(acc[g], thr[g], cnt[g], wave_buf + (int64_t)g * 64 * CAP, i0 + 4 * h, row_end, p,
-                                  (int64_t)qtile * 32 * NB + 32 * g + j);
+        for (int g = 0; g < NB; ++g) {
+            if (partial) mask_tail_rows(acc[g], row0, (int)row_end);
+            tile_filter<KP, false>(acc[g], thr[g], cnt[g], wave_buf + g * 64 * CAP, row0, p, 0);
+        }
+    };
+    int t = 0;
+    if (n_full >= 5) {
+        // steady state: every load is unconditional (a conditional load would make the compiler's wait-count
+        // analysis assume the youngest loads are the ones being waited for, i.e. no prefetch at all)
+        load_tile(a0, 0);
+        load_tile(a1, 1);
+        for (; t + 4 < n_full; t += 3) {
+            load_tile(a2, t + 2);
+            compute_tile(a0, t, false);
+            load_tile(a0, t + 3);
+            compute_tile(a1, t + 1, false);
+            load_tile(a1, t + 4);
+            compute_tile(a2, t + 2, false);
+        }
+    }
+    for (; t < n_full; ++t) {   // the last few full tiles (or a short range): plain load-then-compute
+        load_tile(a2, t);
+        compute_tile(a2, t, false);
+    }
+    if (n_rows_here % 32) {     // partial last tile: rows beyond the range re-read the last valid row, masked to -inf
+        const int64_t r = min(row_begin + 32 * (int64_t)n_full + j, row_end - 1);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+        for (int ks = 0; ks < KS; ++ks)
+            a2[ks] = *reinterpret_cast<const short8*>(p.t_bf16 + r * p.dpad + 16 * ks + 8 * h);
+        compute_tile(a2, n_full, true);
     }
 #pragma unroll
     for (int g = 0; g < NB; ++g)
@@ -242,7 +281,7 @@ __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
 // so stepping k by 2 reproduces the k-ordered fma chain bit for bit.
 template <int KP, bool EXCL>
 __global__ __launch_bounds__(64, 2) void coarse_f32_kernel(CoarseParams p) {
-    constexpr int CAP = 2 * KP;
+    constexpr int CAP = cap_for(KP);
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     int qtile, split;
     decode_wave(p, qtile, split);
@@ -268,7 +307,8 @@ __global__ __launch_bounds__(64, 2) void coarse_f32_kernel(CoarseParams p) {
             const float b = in ? qrow[k] : 0.f;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
-        tile_filter<KP, EXCL>(acc, thr, cnt, wave_buf, i0 + 4 * h, row_end, p, q_global);
+        if (i0 + 32 > row_end) mask_tail_rows(acc, (int)i0 + 4 * h, (int)row_end);
+        tile_filter<KP, EXCL>(acc, thr, cnt, wave_buf, (int)i0 + 4 * h, p, q_global);
     }
     finish_group<KP>(thr, cnt, wave_buf, p.meta_cnt + wave * 64, p.meta_thr + wave * 64);
 }
@@ -279,7 +319,7 @@ struct RescoreParams {
     const float* t_f32;   // (n_rows, d)
     int64_t n_q, n_rows;
     int d;
-    int NB, KP, n_splits;
+    int NB, KP, cap, n_splits;
     const uint2* cand;
     const int* meta_cnt;
     const float* meta_thr;
@@ -306,7 +346,7 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
     const int t = threadIdx.x % TPQ;
     const int64_t q = (int64_t)blockIdx.x * QPB + threadIdx.x / TPQ;
     const bool q_ok = q < p.n_q;
-    const int CAP = 2 * p.KP;
+    const int CAP = p.cap;
     const int n_cand = p.n_splits * 2 * p.KP;
     const int qtile = (int)(q / (32 * p.NB)), g = (int)((q / 32) % p.NB), jq = (int)(q % 32);
     const float* qv = p.q_f32 + (q_ok ? q : 0) * p.d;
@@ -543,18 +583,18 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
     pl.NB = 1;
     if (bf16) pl.NB = n_q >= 16384 ? 4 : (n_q >= 4096 ? 2 : 1);
     if (bf16 && pl.KS == 8 && pl.NB == 4) pl.NB = 2;   // d = 128: four query groups would not fit 256 registers
-    const int64_t qpw = 32 * pl.NB;
+    const int64_t qpw = 32 * pl.NB;   // queries per wave
     pl.chunk = std::min<int64_t>(hmx_ceil_div(n_q, qpw) * qpw, 2048 * qpw);
-    pl.n_qtiles = (int)(pl.chunk / qpw);
+    pl.n_qtiles = (int)(pl.chunk / (32 * pl.NB));
     int64_t s = hmx_ceil_div(2048, pl.n_qtiles);
-    s = std::min<int64_t>(s, 4096 / (2 * pl.KP));              // candidates per query <= 4096
+    s = std::min<int64_t>(s, 8192 / (2 * pl.KP));              // candidates per query <= 8192
     s = std::min<int64_t>(s, std::max<int64_t>(1, n_rows / 2048));
     if (s >= 8) s = s / 8 * 8;                                  // XCD-aware block mapping wants a multiple of 8
     pl.n_splits = (int)std::max<int64_t>(1, s);
     pl.rows_per_split = hmx_ceil_div(hmx_ceil_div(n_rows, pl.n_splits), 32) * 32;
     const int64_t waves = (int64_t)pl.n_qtiles * pl.n_splits;
     pl.q_bf16_bytes = bf16 ? hmx_align_up((size_t)pl.chunk * pl.dpad * 2, 256) : 0;
-    pl.cand_bytes = hmx_align_up((size_t)waves * pl.NB * 64 * (2 * pl.KP) * sizeof(uint2), 256);
+    pl.cand_bytes = hmx_align_up((size_t)waves * pl.NB * 64 * cap_for(pl.KP) * sizeof(uint2), 256);
     pl.meta_bytes = hmx_align_up((size_t)waves * pl.NB * 64 * 4, 256);
     return true;
 }
@@ -562,21 +602,21 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
 // The bf16 coarse pass never looks at the exclusion lists: excluded ids are removed when the shortlist is
 // re-scored, and the completeness proof there covers what they displaced.
 template <int NB, int KS, int KP>
-void launch_bf16(const CoarseParams& p, int waves, bool, hipStream_t s) {
-    hipLaunchKernelGGL((coarse_bf16_kernel<NB, KS, KP, false>), dim3(waves), dim3(64), 0, s, p);
+void launch_bf16(const CoarseParams& p, hipStream_t s) {
+    hipLaunchKernelGGL((coarse_bf16_kernel<NB, KS, KP>), dim3(p.n_qtiles * p.n_splits), dim3(64), 0, s, p);
 }
 template <int NB, int KS>
-void launch_bf16_kp(const CoarseParams& p, int waves, int KP, bool excl, hipStream_t s) {
-    if (KP == 32) launch_bf16<NB, KS, 32>(p, waves, excl, s);
-    else launch_bf16<NB, KS, 64>(p, waves, excl, s);
+void launch_bf16_kp(const CoarseParams& p, int KP, hipStream_t s) {
+    if (KP == 32) launch_bf16<NB, KS, 32>(p, s);
+    else launch_bf16<NB, KS, 64>(p, s);
 }
 template <int NB>
-void launch_bf16_ks(const CoarseParams& p, int waves, int KS, int KP, bool excl, hipStream_t s) {
+void launch_bf16_ks(const CoarseParams& p, int KS, int KP, hipStream_t s) {
     switch (KS) {
-        case 1: launch_bf16_kp<NB, 1>(p, waves, KP, excl, s); break;
-        case 2: launch_bf16_kp<NB, 2>(p, waves, KP, excl, s); break;
-        case 4: launch_bf16_kp<NB, 4>(p, waves, KP, excl, s); break;
-        default: launch_bf16_kp<NB, 8>(p, waves, KP, excl, s); break;
+        case 1: launch_bf16_kp<NB, 1>(p, KP, s); break;
+        case 2: launch_bf16_kp<NB, 2>(p, KP, s); break;
+        case 4: launch_bf16_kp<NB, 4>(p, KP, s); break;
+        default: launch_bf16_kp<NB, 8>(p, KP, s); break;
     }
 }
 
@@ -589,7 +629,8 @@ void launch_rescore(const RescoreParams& r, hipStream_t s) {
     else if (n_cand <= 128) HMX_RS(64, 2);
     else if (n_cand <= 256) HMX_RS(64, 4);
     else if (n_cand <= 1024) HMX_RS(256, 4);
-    else HMX_RS(256, 16);
+    else if (n_cand <= 4096) HMX_RS(256, 16);
+    else HMX_RS(256, 32);
 #undef HMX_RS
 }
 
@@ -640,9 +681,9 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)std::min<int64_t>(hmx_ceil_div(rows_pad, 16), 8192)), dim3(256), 0, s,
                                queries + q0 * d, nq, (int)d, rows_pad, pl.dpad, q_bf16, (unsigned*)nullptr);
             span = hmx_profile_begin("topk_coarse_bf16", s);
-            if (pl.NB == 4) launch_bf16_ks<4>(p, waves, pl.KS, pl.KP, excl, s);
-            else if (pl.NB == 2) launch_bf16_ks<2>(p, waves, pl.KS, pl.KP, excl, s);
-            else launch_bf16_ks<1>(p, waves, pl.KS, pl.KP, excl, s);
+            if (pl.NB == 4) launch_bf16_ks<4>(p, pl.KS, pl.KP, s);
+            else if (pl.NB == 2) launch_bf16_ks<2>(p, pl.KS, pl.KP, s);
+            else launch_bf16_ks<1>(p, pl.KS, pl.KP, s);
         } else {
             span = hmx_profile_begin("topk_coarse_f32", s);
             if (pl.KP == 32) {
@@ -663,6 +704,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
         r.d = (int)d;
         r.NB = pl.NB;
         r.KP = pl.KP;
+        r.cap = cap_for(pl.KP);
         r.n_splits = pl.n_splits;
         r.cand = cand;
         r.meta_cnt = meta_cnt;
