@@ -88,6 +88,17 @@ def cpu_baseline_retrieval(table_host, d, k, seconds_target=10.0):
                       f"torch.mm+topk fp32 on {threads} threads ({dt:.1f} s)"}
 
 
+def pmc_traffic(name):
+    """HBM bytes per launch of the dominant kernel from the committed counter summary (collected in separate
+    rocprofv3 --pmc runs; a benchmark run cannot collect them itself).  None when no summary is present."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    return d.get("hbm_bytes_per_launch"), f"profiles/{name}: {d.get('launch', '')}"
+
+
 def run_retrieval(args, world, rank):
     from generative_recommenders_amd import hmx, synth
     from generative_recommenders_amd.retrieval import ShardedRetriever, shard_bounds
@@ -121,6 +132,7 @@ def run_retrieval(args, world, rank):
     # dominant kernel: bf16 MFMA coarse scoring.  Algorithmic flops per launch = 2 * queries * rows * d.
     flops_per_step = 2.0 * args.queries * (hi - lo) * d
     achieved = flops_per_step * args.steps / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic("r01_retrieval_pmc.json") if world == 1 else (None, None)
     out = {
         "metric": "top-10 queries/s over 4M items", "value": args.queries / step_s, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
@@ -130,8 +142,9 @@ def run_retrieval(args, world, rank):
                    "queries": args.queries, "items": n_rows, "d": d, "k": k,
                    "parallelism": f"item-range shards x{world}, all_gather merge" if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                     "kernel": "coarse_bf16_kernel", "launches": k_launches,
+                     "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "HBM bytes per full 262144-query launch (FETCH_SIZE x 2 + WRITE_SIZE)",
+                     "traffic_source": traffic_src, "kernel": "coarse_bf16_kernel", "launches": k_launches,
                      "avg_launch_ms": k_ms / max(k_launches, 1)},
         "uncertain_queries_rerun_exact": uncertain,
     }
