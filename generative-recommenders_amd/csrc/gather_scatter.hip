@@ -35,6 +35,13 @@ __device__ __forceinline__ float vzero<1>() { return 0.f; }
 __device__ __forceinline__ void vadd(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
 
+using f32x4_native = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void nt_store(const float4& v, float4* p) {
+    f32x4_native x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<f32x4_native*>(p));
+}
+__device__ __forceinline__ void nt_store(const float& v, float* p) { __builtin_nontemporal_store(v, p); }
+
 // ROUTED: 0 = single table; 1 = item/user tables selected by token type (1 / 2, else zeros).
 template <int VEC, bool ROUTED>
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ table0, int64_t rows0,
@@ -73,7 +80,9 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 const int64_t r = base + (int64_t)u * rows_per_block;
-                if (r < n) reinterpret_cast<V*>(out)[r * cpr + c] = v[u];
+                // streaming store: the gathered copy is not read again by this kernel, so it should not evict
+                // table rows (which repeat) from L2 / Infinity Cache
+                if (r < n) nt_store(v[u], reinterpret_cast<V*>(out) + r * cpr + c);
             }
         }
     }

@@ -7,7 +7,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhmx.so")
+LIB_PATH = os.environ.get("HMX_LIBRARY", os.path.join(_HERE, "libhmx.so"))
 
 P = c_void_p
 I64 = c_int64
