@@ -1,0 +1,481 @@
+// Fused InfoNCE loss over [positive | hard negatives gathered from the item table | in-batch negatives]
+// (hydra3.py:845-974): the (M, 1 + n_hard + n_inb, d) key tensor of the reference is never materialised.
+//
+// Per query row i:   logit[c] = <q_i / |q_i|, key_c / |key_c|> / temperature,   loss_i = logsumexp(logit) - logit[0]
+//   key_0          = k[i]                       (its positive)
+//   key_1..n_hard  = table[hard_ids[i, .]]      (row gather from the item table, normalised on the fly)
+//   key_rest       = k[inb_idx[i, .]]           (other rows of the same batch)
+//
+// Geometry: one wave per query; 16 lanes x 16 B cover one key row (d <= 256), so a wave handles four keys per
+// step and keeps four steps of row loads in flight.  Row sums use DPP inside a 16-lane row (no LDS).
+// Backward: the same traversal yields d q and one coefficient per (query, key); the key gradients are the
+// transposed sparse product  sum_i coef[i, c] * q_i  accumulated per destination row with the deterministic
+// sorted-run sum shared with the embedding backward, followed by the normalisation Jacobian applied once per
+// destination row (it is linear, so it commutes with the sum).
+#include "segment_sum.h"
+#include "profile.h"
+
+namespace {
+
+using namespace hmx_seg;
+
+constexpr int kStepsInFlight = 4;
+constexpr float kNormEps = 1e-12f;   // F.normalize(eps=1e-12)
+
+struct NceParams {
+    const float* q;           // (m, d)
+    const float* k;           // (m, d)
+    int64_t m;
+    int d, cpr;               // cpr = d / 4
+    const float* table;       // (n_rows, d)
+    int64_t n_rows;
+    const int64_t* hard_ids;  // (m, n_hard)
+    int n_hard;
+    const int64_t* inb_idx;   // (m, n_inb)
+    int n_inb;
+    float inv_temp;
+    int normalize;
+    float* logits;            // (m, C): logits after forward, key-gradient coefficients after backward
+    float* row_loss;          // (m)
+    float* lse;               // (m)
+    float* q_inv;             // (m) 1 / max(|q_i|, eps)   (1 when normalize == 0)
+    float* k_inv;             // (m)
+    const float* grad_row_loss;   // (m)   backward only
+    float* dq;                    // (m, d) backward only
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row; every lane of the row receives the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0x128>(v);   // row_ror:8
+    v += dpp_f32<0x124>(v);   // row_ror:4
+    v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    return v;
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// one group of 16 lanes per row: out[i] = 1 / max(|x_i|, eps)
+__global__ __launch_bounds__(256) void inv_norm_kernel(const float* __restrict__ x, int64_t m, int cpr, int normalize,
+                                                       float* __restrict__ out) {
+    const int lc = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    float ss = 0.f;
+    if (i < m && normalize)
+        for (int c = lc; c < cpr; c += 16) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i * cpr + c];
+            ss += dot4(v, v);
+        }
+    ss = row16_sum(ss);
+    if (i < m && lc == 0) out[i] = normalize ? 1.0f / fmaxf(sqrtf(ss), kNormEps) : 1.0f;
+}
+
+// Where key `slot` of query i lives.  kind: 0 = absent (zero key), 1 = row of k (inverse norm known), 2 = table row.
+struct KeyRef {
+    const float4* src;
+    float inv;
+    int kind;
+};
+__device__ __forceinline__ KeyRef locate_key(const NceParams& p, int64_t i, int slot, int C) {
+    KeyRef r{nullptr, 0.f, 0};
+    if (slot >= C) return r;
+    if (slot == 0) {
+        r.src = reinterpret_cast<const float4*>(p.k) + i * p.cpr;
+        r.inv = p.k_inv[i];
+        r.kind = 1;
+    } else if (slot <= p.n_hard) {
+        const int64_t id = p.hard_ids[i * p.n_hard + slot - 1];
+        if (id >= 0 && id < p.n_rows) {
+            r.src = reinterpret_cast<const float4*>(p.table) + id * p.cpr;
+            r.kind = 2;
+        }
+    } else {
+        const int64_t j = p.inb_idx[i * p.n_inb + slot - 1 - p.n_hard];
+        if (j >= 0 && j < p.m) {
+            r.src = reinterpret_cast<const float4*>(p.k) + j * p.cpr;
+            r.inv = p.k_inv[j];
+            r.kind = 1;
+        }
+    }
+    return r;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
+    const int lane = threadIdx.x & 63, grp = lane >> 4, lc = lane & 15;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.m) return;   // wave-uniform
+    const int C = 1 + p.n_hard + p.n_inb;
+    float4 qv[NCH];
+    const float qs = p.q_inv[i] * p.inv_temp;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = lc + 16 * ch;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < p.cpr) v = reinterpret_cast<const float4*>(p.q)[i * p.cpr + c];
+        qv[ch] = make_float4(v.x * qs, v.y * qs, v.z * qs, v.w * qs);
+    }
+    float mx = -INFINITY, sm = 0.f, l0 = 0.f;
+    for (int c0 = 0; c0 < C; c0 += 4 * kStepsInFlight) {
+        KeyRef ref[kStepsInFlight];
+        float4 v[kStepsInFlight][NCH];
+#pragma unroll
+        for (int u = 0; u < kStepsInFlight; ++u) ref[u] = locate_key(p, i, c0 + 4 * u + grp, C);
+#pragma unroll
+        for (int u = 0; u < kStepsInFlight; ++u)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = lc + 16 * ch;
+                v[u][ch] = (ref[u].kind != 0 && c < p.cpr) ? ref[u].src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < kStepsInFlight; ++u) {
+            const int slot = c0 + 4 * u + grp;
+            float dot = 0.f, ss = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                dot += dot4(v[u][ch], qv[ch]);
+                ss += dot4(v[u][ch], v[u][ch]);
+            }
+            dot = row16_sum(dot);
+            float inv = ref[u].inv;
+            if (ref[u].kind == 2) {
+                ss = row16_sum(ss);
+                inv = p.normalize ? 1.0f / fmaxf(sqrtf(ss), kNormEps) : 1.0f;
+            }
+            const float logit = dot * inv;
+            if (slot < C) {
+                if (lc == 0) p.logits[i * C + slot] = logit;
+                const float nm = fmaxf(mx, logit);
+                sm = sm * expf(mx - nm) + expf(logit - nm);   // exp(-inf) = 0 on the first key
+                mx = nm;
+                if (slot == 0) l0 = logit;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float om = __shfl_xor(mx, off), os = __shfl_xor(sm, off);
+        const float nm = fmaxf(mx, om);
+        const float a = (mx == -INFINITY) ? 0.f : sm * expf(mx - nm);
+        const float b = (om == -INFINITY) ? 0.f : os * expf(om - nm);
+        sm = a + b;
+        mx = nm;
+    }
+    l0 = __shfl(l0, 0);
+    if (lane == 0) {
+        const float lse = mx + logf(sm);
+        p.lse[i] = lse;
+        p.row_loss[i] = lse - l0;
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
+    const int lane = threadIdx.x & 63, grp = lane >> 4, lc = lane & 15;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.m) return;
+    const int C = 1 + p.n_hard + p.n_inb;
+    const float qinv = p.q_inv[i], lse = p.lse[i], g = p.grad_row_loss[i] * p.inv_temp;
+    float4 qn[NCH], acc[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = lc + 16 * ch;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < p.cpr) v = reinterpret_cast<const float4*>(p.q)[i * p.cpr + c];
+        qn[ch] = make_float4(v.x * qinv, v.y * qinv, v.z * qinv, v.w * qinv);
+        acc[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int c0 = 0; c0 < C; c0 += 4 * kStepsInFlight) {
+        KeyRef ref[kStepsInFlight];
+        float4 v[kStepsInFlight][NCH];
+        float lg[kStepsInFlight];
+#pragma unroll
+        for (int u = 0; u < kStepsInFlight; ++u) {
+            const int slot = c0 + 4 * u + grp;
+            ref[u] = locate_key(p, i, slot, C);
+            lg[u] = slot < C ? p.logits[i * C + slot] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kStepsInFlight; ++u)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = lc + 16 * ch;
+                v[u][ch] = (ref[u].kind != 0 && c < p.cpr) ? ref[u].src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < kStepsInFlight; ++u) {
+            const int slot = c0 + 4 * u + grp;
+            float inv = ref[u].inv;
+            if (ref[u].kind == 2) {
+                float ss = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) ss += dot4(v[u][ch], v[u][ch]);
+                ss = row16_sum(ss);
+                inv = p.normalize ? 1.0f / fmaxf(sqrtf(ss), kNormEps) : 1.0f;
+            }
+            if (slot < C) {
+                const float w = (expf(lg[u] - lse) - (slot == 0 ? 1.f : 0.f)) * g;   // dL / d <qn, keyn>
+                const float wk = w * inv;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    acc[ch].x += wk * v[u][ch].x;
+                    acc[ch].y += wk * v[u][ch].y;
+                    acc[ch].z += wk * v[u][ch].z;
+                    acc[ch].w += wk * v[u][ch].w;
+                }
+                // d keyn = w * qn = (w * qinv) * q_i: the coefficient of q_i in the destination row's sum
+                if (lc == 0) p.logits[i * C + slot] = w * qinv;
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            acc[ch].x += __shfl_xor(acc[ch].x, off);
+            acc[ch].y += __shfl_xor(acc[ch].y, off);
+            acc[ch].z += __shfl_xor(acc[ch].z, off);
+            acc[ch].w += __shfl_xor(acc[ch].w, off);
+        }
+    }
+    // acc = dL / d qn.  Through qn = q / max(|q|, eps):  dq = qinv * (acc - qn <qn, acc>) when |q| > eps, else qinv * acc
+    float pr = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) pr += dot4(qn[ch], acc[ch]);
+    pr = row16_sum(pr);
+    if (!p.normalize || qinv >= 1.0f / kNormEps) pr = 0.f;
+    if (grp == 0) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = lc + 16 * ch;
+            if (c < p.cpr) {
+                float4 o;
+                o.x = qinv * (acc[ch].x - qn[ch].x * pr);
+                o.y = qinv * (acc[ch].y - qn[ch].y * pr);
+                o.z = qinv * (acc[ch].z - qn[ch].z * pr);
+                o.w = qinv * (acc[ch].w - qn[ch].w * pr);
+                reinterpret_cast<float4*>(p.dq)[i * p.cpr + c] = o;
+            }
+        }
+    }
+}
+
+// In place on one gradient row G that belongs to raw row x with inverse norm `inv`:
+//   G <- inv * (G - xn <xn, G>),  xn = x * inv      (inv * G when the norm was clamped)
+__device__ __forceinline__ void project_row(float4* g_row, const float4* x_row, float inv, float extra_coef,
+                                            const float4* extra_row, int cpr, int lc, int normalize) {
+    float4 g[4], xn[4];
+    float pr = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const int c = lc + 16 * ch;
+        g[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xn[ch] = g[ch];
+        if (c < cpr) {
+            g[ch] = g_row[c];
+            if (extra_row != nullptr) {
+                const float4 e = extra_row[c];
+                g[ch].x += extra_coef * e.x;
+                g[ch].y += extra_coef * e.y;
+                g[ch].z += extra_coef * e.z;
+                g[ch].w += extra_coef * e.w;
+            }
+            const float4 x = x_row[c];
+            xn[ch] = make_float4(x.x * inv, x.y * inv, x.z * inv, x.w * inv);
+            pr += dot4(xn[ch], g[ch]);
+        }
+    }
+    pr = row16_sum(pr);
+    float s = inv;
+    if (!normalize) {
+        pr = 0.f;
+        s = 1.f;
+    } else if (inv >= 1.0f / kNormEps) {
+        pr = 0.f;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const int c = lc + 16 * ch;
+        if (c < cpr) {
+            float4 o;
+            o.x = s * (g[ch].x - xn[ch].x * pr);
+            o.y = s * (g[ch].y - xn[ch].y * pr);
+            o.z = s * (g[ch].z - xn[ch].z * pr);
+            o.w = s * (g[ch].w - xn[ch].w * pr);
+            g_row[c] = o;
+        }
+    }
+}
+
+// dk[j] <- Jacobian of normalisation applied to (dk[j] + coef[j, 0] * q[j])
+__global__ __launch_bounds__(256) void nce_finish_k_kernel(NceParams p, float* __restrict__ dk) {
+    const int lc = threadIdx.x & 15;
+    const int64_t j = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int C = 1 + p.n_hard + p.n_inb;
+    const bool ok = j < p.m;
+    const int64_t jj = ok ? j : 0;
+    // every lane of a DPP row takes part in row16_sum, so out-of-range groups run on row 0 and skip the store
+    if (ok)
+        project_row(reinterpret_cast<float4*>(dk) + jj * p.cpr, reinterpret_cast<const float4*>(p.k) + jj * p.cpr,
+                    p.k_inv[jj], p.logits[jj * C], reinterpret_cast<const float4*>(p.q) + jj * p.cpr, p.cpr, lc,
+                    p.normalize);
+}
+
+// Table rows that received hard-negative gradient: one 16-lane group per position of the sorted key array acts
+// where a run of equal keys starts, i.e. exactly once per distinct row.
+__global__ __launch_bounds__(256) void nce_project_table_rows_kernel(const uint32_t* __restrict__ skeys, int64_t n,
+                                                                     uint32_t sentinel, const float* __restrict__ table,
+                                                                     int cpr, float* __restrict__ dtable) {
+    const int lc = threadIdx.x & 15;
+    for (int64_t e = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); e < n; e += (int64_t)gridDim.x * 16) {
+        const uint32_t key = skeys[e];
+        if (key == sentinel) break;   // sentinels sort last (uniform inside a 16-lane row; rows of a wave may differ)
+        if (e > 0 && skeys[e - 1] == key) continue;
+        const float4* x = reinterpret_cast<const float4*>(table) + (int64_t)key * cpr;
+        float ss = 0.f;
+        for (int c = lc; c < cpr; c += 16) {
+            const float4 v = x[c];
+            ss += dot4(v, v);
+        }
+        ss = row16_sum(ss);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), kNormEps);
+        project_row(reinterpret_cast<float4*>(dtable) + (int64_t)key * cpr, x, inv, 0.f, nullptr, cpr, lc, 1);
+    }
+}
+
+bool nce_shape_ok(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb) {
+    if (m <= 0 || d <= 0 || d % 4 != 0 || d > 256 || n_hard < 0 || n_inb < 0) return false;
+    if (n_hard > 0 && n_rows <= 0) return false;
+    if (m >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 31)) return false;
+    if (m * (n_hard > n_inb ? n_hard : n_inb) >= ((int64_t)1 << 32)) return false;
+    if (1 + n_hard + n_inb > (1 << 20)) return false;
+    return true;
+}
+
+NceParams make_params(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
+                      const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
+                      float temperature, int normalize, float* logits, float* row_loss, float* lse, float* q_inv,
+                      float* k_inv) {
+    NceParams p{};
+    p.q = q;
+    p.k = k;
+    p.m = m;
+    p.d = (int)d;
+    p.cpr = (int)(d / 4);
+    p.table = table;
+    p.n_rows = n_rows;
+    p.hard_ids = hard_ids;
+    p.n_hard = (int)n_hard;
+    p.inb_idx = inb_idx;
+    p.n_inb = (int)n_inb;
+    p.inv_temp = 1.0f / temperature;
+    p.normalize = normalize;
+    p.logits = logits;
+    p.row_loss = row_loss;
+    p.lse = lse;
+    p.q_inv = q_inv;
+    p.k_inv = k_inv;
+    return p;
+}
+
+bool aligned16(const void* a) { return (reinterpret_cast<uintptr_t>(a) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
+                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
+                               int64_t n_inb, float temperature, int normalize, float* logits, float* row_loss,
+                               float* lse, float* q_inv, float* k_inv, void* stream) {
+    HMX_ENTER();
+    if (m == 0) return HMX_OK;
+    if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb) || !(temperature > 0.f)) return HMX_EINVAL;
+    if (!q || !k || !logits || !row_loss || !lse || !q_inv || !k_inv) return HMX_EINVAL;
+    if ((n_hard > 0 && (!table || !hard_ids)) || (n_inb > 0 && !inb_idx)) return HMX_EINVAL;
+    if (!aligned16(q) || !aligned16(k) || (n_hard > 0 && !aligned16(table))) return HMX_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize,
+                              logits, row_loss, lse, q_inv, k_inv);
+    const unsigned g16 = (unsigned)hmx_ceil_div(m, 16), g4 = (unsigned)hmx_ceil_div(m, 4);
+    hipLaunchKernelGGL(inv_norm_kernel, dim3(g16), dim3(256), 0, s, q, m, p.cpr, normalize, q_inv);
+    hipLaunchKernelGGL(inv_norm_kernel, dim3(g16), dim3(256), 0, s, k, m, p.cpr, normalize, k_inv);
+    void* span = hmx_profile_begin("nce_fwd", s);
+    if (p.cpr <= 16) hipLaunchKernelGGL(nce_fwd_kernel<1>, dim3(g4), dim3(256), 0, s, p);
+    else if (p.cpr <= 32) hipLaunchKernelGGL(nce_fwd_kernel<2>, dim3(g4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(nce_fwd_kernel<4>, dim3(g4), dim3(256), 0, s, p);
+    hmx_profile_end(span, s);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" size_t hmx_nce_bwd_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb) {
+    if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb)) return 256;
+    size_t a = n_inb > 0 ? hmx_seg::workspace_bytes(m * n_inb, m, d) : 256;
+    size_t b = n_hard > 0 ? hmx_seg::workspace_bytes(m * n_hard, n_rows, d) : 256;
+    return a > b ? a : b;
+}
+
+extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
+                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
+                               int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
+                               const float* q_inv, const float* k_inv, const float* grad_row_loss, float* dq,
+                               float* dk, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
+    HMX_ENTER();
+    if (m == 0) return HMX_OK;
+    if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb) || !(temperature > 0.f)) return HMX_EINVAL;
+    if (!q || !k || !logits || !lse || !q_inv || !k_inv || !grad_row_loss || !dq || !dk || !workspace)
+        return HMX_EINVAL;
+    if ((n_hard > 0 && (!table || !hard_ids || !dtable)) || (n_inb > 0 && !inb_idx)) return HMX_EINVAL;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(dq) || !aligned16(dk) ||
+        (n_hard > 0 && (!aligned16(table) || !aligned16(dtable))))
+        return HMX_EINVAL;
+    if (workspace_bytes < hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb)) return HMX_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize,
+                              logits, nullptr, const_cast<float*>(lse), const_cast<float*>(q_inv),
+                              const_cast<float*>(k_inv));
+    p.grad_row_loss = grad_row_loss;
+    p.dq = dq;
+    const int C = (int)(1 + n_hard + n_inb);
+    const unsigned g16 = (unsigned)hmx_ceil_div(m, 16), g4 = (unsigned)hmx_ceil_div(m, 4);
+    void* span = hmx_profile_begin("nce_bwd", s);
+    if (p.cpr <= 16) hipLaunchKernelGGL(nce_bwd_q_kernel<1>, dim3(g4), dim3(256), 0, s, p);
+    else if (p.cpr <= 32) hipLaunchKernelGGL(nce_bwd_q_kernel<2>, dim3(g4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(nce_bwd_q_kernel<4>, dim3(g4), dim3(256), 0, s, p);
+    HMX_CHECK_LAUNCH();
+    // d k: in-batch references (transposed sparse product), then the row's own positive term + normalisation
+    if (hipMemsetAsync(dk, 0, (size_t)m * d * sizeof(float), s) != hipSuccess) return HMX_ELAUNCH;
+    if (n_inb > 0) {
+        WeightedRows src{q, logits, (int)n_inb, C, (int)(1 + n_hard)};
+        const int rc = sorted_segment_add(src, true, inb_idx, nullptr, 0, m * n_inb, d, dk, m, -1, workspace,
+                                          workspace_bytes, s);
+        if (rc != HMX_OK) return rc;
+    }
+    hipLaunchKernelGGL(nce_finish_k_kernel, dim3(g16), dim3(256), 0, s, p, dk);
+    HMX_CHECK_LAUNCH();
+    // d table: hard-negative references, then the normalisation of each touched row (dtable holds only this
+    // call's sums: it must be zero on entry)
+    if (n_hard > 0) {
+        WeightedRows src{q, logits, (int)n_hard, C, 1};
+        const uint32_t* skeys = nullptr;
+        uint32_t sentinel = 0;
+        const int rc = sorted_segment_add(src, true, hard_ids, nullptr, 0, m * n_hard, d, dtable, n_rows, -1,
+                                          workspace, workspace_bytes, s, &skeys, &sentinel);
+        if (rc != HMX_OK) return rc;
+        if (normalize) {
+            const int64_t n = m * n_hard;
+            const unsigned grid = (unsigned)std::min<int64_t>(hmx_ceil_div(n, 16), 65536);
+            hipLaunchKernelGGL(nce_project_table_rows_kernel, dim3(grid), dim3(256), 0, s, skeys, n, sentinel, table,
+                               p.cpr, dtable);
+            HMX_CHECK_LAUNCH();
+        }
+    }
+    hmx_profile_end(span, s);
+    return HMX_OK;
+}

@@ -237,53 +237,44 @@ def _sample_inbatch_indices_no_self(M, rows, T, device):
 
 def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=None, hard_negatives=None, T=512,
                                    hard_ratio=0.3, temperature=0.05, normalize=True, q_chunk=64, device=None):
-    """hydra3.py:845-974 (InfoNCE over in-batch + hard negatives).  PyTorch ops on the GPU, except the hard-negative
-    row gather `item_table[ids]` (hydra3.py:917), which is the HIP gather with its scatter-add backward."""
+    """hydra3.py:845-974 (InfoNCE over in-batch + hard negatives).  The negatives are drawn here exactly as the
+    reference draws them (index tensors only); the loss itself -- hard-negative row gather, normalisation, the
+    (M, 513) logits, log-softmax and the whole backward incl. the scatter into the item-table gradient -- is one
+    fused HIP op, so no (M, 513, d) key tensor exists.  `q_chunk` only bounded the reference's memory use and has
+    no effect on the value; it is accepted and ignored."""
     device = log_feats.device
     mask = loss_mask.bool()
     q, k = log_feats[mask], pos_embs[mask]
     M = q.shape[0]
     if M == 0:
         return torch.tensor(0.0, device=device, requires_grad=True)
-    if normalize:
-        q, k = F.normalize(q, p=2, dim=-1), F.normalize(k, p=2, dim=-1)
     num_hard = int(T * hard_ratio)
     num_inb = T - num_hard
-    hard_ids = hard_negatives[mask] if hard_negatives is not None else None
-    rows = torch.arange(M, device=device)
-    losses = []
-    for s in range(0, M, q_chunk):
-        e = min(s + q_chunk, M)
-        n = e - s
-        negs = []
-        if hard_ids is not None and num_hard > 0:
-            ch = hard_ids[s:e]
-            K = ch.shape[1]
-            if K >= num_hard:
-                ch = torch.gather(ch, 1, torch.randint(0, K, (n, num_hard), device=device))
-            else:
-                ch = ch.repeat(1, (num_hard + K - 1) // K)[:, :num_hard]
-            hn = ops.gather_rows(item_table, ch.contiguous())
-            negs.append(F.normalize(hn, p=2, dim=-1) if normalize else hn)
-        if num_inb > 0:
-            if M - 1 >= num_inb:
-                inb = k[_sample_inbatch_indices_no_self(M, rows[s:e], num_inb, device)]
-            else:
-                base = torch.arange(M, device=device).unsqueeze(0).repeat(M, 1)
-                inb = k[base[base != rows.unsqueeze(1)].view(M, M - 1)[s:e]]
-                short = num_inb - inb.shape[1]
-                if short > 0:
-                    if item_table is not None:
-                        rid = torch.randint(1, item_table.shape[0], (n, short), device=device)
-                        re_ = ops.gather_rows(item_table, rid)
-                        inb = torch.cat([inb, F.normalize(re_, p=2, dim=-1) if normalize else re_], dim=1)
-                    else:
-                        inb = torch.cat([inb, inb[:, -1:].expand(-1, short, -1)], dim=1)
-            negs.append(inb)
-        keys = torch.cat([k[s:e].unsqueeze(1)] + negs, dim=1)
-        logits = (q[s:e].unsqueeze(1) * keys).sum(-1) / temperature
-        losses.append(-F.log_softmax(logits, dim=1)[:, 0])
-    return torch.cat(losses, dim=0).mean()
+    hard_ids = None
+    if hard_negatives is not None and num_hard > 0:                      # hydra3.py:905-919
+        ch = hard_negatives[mask]
+        K = ch.shape[1]
+        if K >= num_hard:
+            ch = torch.gather(ch, 1, torch.randint(0, K, (M, num_hard), device=device))
+        else:
+            ch = ch.repeat(1, (num_hard + K - 1) // K)[:, :num_hard]
+        hard_ids = ch
+    inb = None
+    if num_inb > 0:                                                      # hydra3.py:921-950
+        rows = torch.arange(M, device=device)
+        if M - 1 >= num_inb:
+            inb = _sample_inbatch_indices_no_self(M, rows, num_inb, device)
+        else:
+            base = rows.unsqueeze(0).repeat(M, 1)
+            inb = base[base != rows.unsqueeze(1)].view(M, M - 1)
+            short = num_inb - (M - 1)
+            if short > 0:
+                if item_table is not None:       # random table rows fill the batch's shortfall: more table keys
+                    rid = torch.randint(1, item_table.shape[0], (M, short), device=device)
+                    hard_ids = rid if hard_ids is None else torch.cat([hard_ids, rid], dim=1)
+                else:
+                    inb = torch.cat([inb, inb[:, -1:].expand(-1, short)], dim=1)
+    return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize).mean()
 
 
 class EnhancedTrainingLoss(nn.Module):

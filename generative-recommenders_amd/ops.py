@@ -115,6 +115,61 @@ def gather_routed(item_weight, user_weight, ids, token_type):
     return _GatherRouted.apply(item_weight, user_weight, ids, token_type)
 
 
+# --------------------------------------------------------------------------- fused InfoNCE
+class _FusedNCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, table, hard_ids, inb_idx, temperature, normalize):
+        _need_cuda(q, k, table, hard_ids, inb_idx)
+        q, k = _f32c(q), _f32c(k)
+        m, d = q.shape
+        assert k.shape == (m, d)
+        n_hard = 0 if hard_ids is None else hard_ids.shape[1]
+        n_inb = 0 if inb_idx is None else inb_idx.shape[1]
+        tab = _f32c(table.detach()) if (table is not None and n_hard > 0) else None
+        hid = _i64c(hard_ids) if n_hard > 0 else None
+        iid = _i64c(inb_idx) if n_inb > 0 else None
+        dev = q.device
+        logits = torch.empty(m, 1 + n_hard + n_inb, dtype=torch.float32, device=dev)
+        row_loss, lse, q_inv, k_inv = (torch.empty(m, dtype=torch.float32, device=dev) for _ in range(4))
+        n_rows = 0 if tab is None else tab.shape[0]
+        hmx.check(hmx.lib().hmx_nce_fwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
+                                            hmx.ptr(iid), n_inb, float(temperature), int(bool(normalize)),
+                                            hmx.ptr(logits), hmx.ptr(row_loss), hmx.ptr(lse), hmx.ptr(q_inv),
+                                            hmx.ptr(k_inv), hmx.current_stream()), "hmx_nce_fwd_f32")
+        ctx.save_for_backward(q, k, tab, hid, iid, logits, lse, q_inv, k_inv)
+        ctx.cfg = (float(temperature), int(bool(normalize)), n_rows, n_hard, n_inb)
+        return row_loss
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        q, k, tab, hid, iid, logits, lse, q_inv, k_inv = ctx.saved_tensors
+        temperature, normalize, n_rows, n_hard, n_inb = ctx.cfg
+        m, d = q.shape
+        dev = q.device
+        g = _f32c(grad_rows)
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        want_table = n_hard > 0 and ctx.needs_input_grad[2]
+        # the hard-negative rows always receive their sums (the kernel has one code path); without a table
+        # gradient wanted, n_hard = 0 is passed for the key-gradient half by handing no destination
+        dtable = torch.zeros(n_rows, d, dtype=torch.float32, device=dev) if n_hard > 0 else None
+        L = hmx.lib()
+        ws = workspace(L.hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb), dev)
+        coef = logits   # overwritten with the key-gradient coefficients: backward may run once
+        hmx.check(L.hmx_nce_bwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
+                                    hmx.ptr(iid), n_inb, temperature, normalize, hmx.ptr(coef), hmx.ptr(lse),
+                                    hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq), hmx.ptr(dk),
+                                    hmx.ptr(dtable), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
+                  "hmx_nce_bwd_f32")
+        return dq, dk, (dtable if want_table else None), None, None, None, None
+
+
+def fused_nce_rows(q, k, table, hard_ids, inb_idx, temperature=0.05, normalize=True):
+    """Per-row InfoNCE loss over [positive k_i | table[hard_ids[i]] | k[inb_idx[i]]] (hydra3.py:845-974 with the
+    sampling done by the caller).  q, k: (M, d); hard_ids: (M, n_hard) item-table rows or None; inb_idx:
+    (M, n_inb) rows of k or None.  Gradients flow to q, k and table.  backward() may run once."""
+    return _FusedNCE.apply(q, k, table, hard_ids, inb_idx, temperature, normalize)
+
+
 # --------------------------------------------------------------------------- scoring + top-K
 def _dpad(d):
     p = 16

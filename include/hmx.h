@@ -110,6 +110,33 @@ int hmx_score_topk_bf16(const float* queries, int64_t n_q, const float* table, c
 int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_shards, int64_t n_q, int64_t k,
                    int64_t* out_ids, float* out_scores, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Fused InfoNCE loss (compute_mixed_contrastive_loss, hydra3.py:845-974).
+ * For every query row i of q (m, d):
+ *   logit[i, 0]                = <q_i^, k_i^> / temperature                     (positive, hydra3.py:958)
+ *   logit[i, 1 .. n_hard]      = <q_i^, table[hard_ids[i, .]]^> / temperature   (hard negatives gathered from the
+ *                                                                                item table, hydra3.py:917-919)
+ *   logit[i, 1 + n_hard .. ]   = <q_i^, k[inb_idx[i, .]]^> / temperature        (in-batch negatives, hydra3.py:925-950)
+ *   row_loss[i]                = logsumexp(logit[i, :]) - logit[i, 0]            (hydra3.py:965-967)
+ * x^ = x / max(|x|, 1e-12) when normalize != 0 (F.normalize), else x.  An id / index out of range is a zero key.
+ * The caller draws hard_ids and inb_idx (any sampling policy) and takes the mean of row_loss.
+ * Forward leaves logits (m, 1 + n_hard + n_inb), lse (m), q_inv (m), k_inv (m) for the backward pass.
+ * Backward takes grad_row_loss (m) and produces dq (m, d), dk (m, d) (both overwritten) and, when n_hard > 0,
+ * ADDS the hard-negative gradient rows into dtable (n_rows, d), which must be zero on entry (the normalisation
+ * Jacobian is applied in place to the rows it touched).  `logits` is overwritten.  d % 4 == 0, d <= 256,
+ * 16-byte aligned q / k / table / dq / dk / dtable.  Deterministic (sorted-run sums, no float atomics).
+ * --------------------------------------------------------------------------------- */
+int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
+                    const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
+                    float temperature, int normalize, float* logits, float* row_loss, float* lse, float* q_inv,
+                    float* k_inv, void* stream);
+size_t hmx_nce_bwd_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb);
+int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
+                    const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
+                    float temperature, int normalize, float* logits, const float* lse, const float* q_inv,
+                    const float* k_inv, const float* grad_row_loss, float* dq, float* dk, float* dtable,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* =================================================================================
  * Sequence encoder (hydra3.py).  Activations are (T = B*L tokens, features) row-major fp32.
  * Forward and backward of every stage; the Python modules chain them under autograd.

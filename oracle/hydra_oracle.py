@@ -323,8 +323,28 @@ class HardNegativeMiner:
 # loss (hydra3.py:817-974, 1085-1151).  Same RNG call sequence as the reference
 # so that, under one torch.manual_seed on CPU, the sampled indices coincide.
 # ----------------------------------------------------------------------------
+def nce_rows(q, k, table, hard_ids, inb_idx, temperature=0.05, normalize=True):
+    """Index form of hydra3.py:845-974: the per-row loss for GIVEN negatives.  Keys of row i are
+    [k_i | table[hard_ids[i]] | k[inb_idx[i]]]; logits = <q^, key^> / temperature (hydra3.py:958-962);
+    loss_i = -log_softmax(logits)[0] (hydra3.py:965-967).  compute_mixed_contrastive_loss below is this function
+    applied to the indices it samples (checked in tests/test_oracle_golden.py)."""
+    if normalize:
+        q, k = F.normalize(q, dim=-1), F.normalize(k, dim=-1)
+    keys = [k.unsqueeze(1)]
+    if hard_ids is not None and hard_ids.shape[1] > 0:
+        hn = table[hard_ids]
+        keys.append(F.normalize(hn, dim=-1) if normalize else hn)
+    if inb_idx is not None and inb_idx.shape[1] > 0:
+        keys.append(k[inb_idx])
+    logits = (q.unsqueeze(1) * torch.cat(keys, dim=1)).sum(-1) / temperature
+    return -F.log_softmax(logits, dim=1)[:, 0]
+
+
 def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=None, hard_negatives=None,
-                                   T=512, hard_ratio=0.3, temperature=0.05, normalize=True, q_chunk=64, device=None):
+                                   T=512, hard_ratio=0.3, temperature=0.05, normalize=True, q_chunk=64, device=None,
+                                   record=None):
+    """record: optional dict that receives the sampled indices ('hard' (M, .) item-table rows incl. the random
+    fill rows of the short-batch case, 'inb' (M, .) rows of the masked positives) for use with nce_rows."""
     mask = loss_mask.bool()
     q, k = log_feats[mask], pos_embs[mask]
     M = q.shape[0]
@@ -337,6 +357,7 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
     hard_ids = hard_negatives[mask] if hard_negatives is not None else None
     rows = torch.arange(M)
     losses = []
+    rec_hard, rec_inb = [], []
     for s in range(0, M, q_chunk):
         e = min(s + q_chunk, M)
         n = e - s
@@ -350,26 +371,37 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
                 ch = ch.repeat(1, (num_hard + K - 1) // K)[:, :num_hard]
             hn = item_table[ch]
             negs.append(F.normalize(hn, dim=-1) if normalize else hn)
+            rec_hard.append([ch])
+        else:
+            rec_hard.append([])
         if num_inb > 0:
             if M - 1 >= num_inb:
                 r = torch.randint(0, M - 1, (n, num_inb))
-                inb = k[r + (r >= rows[s:e].unsqueeze(1)).long()]
+                rec_inb.append(r + (r >= rows[s:e].unsqueeze(1)).long())
+                inb = k[rec_inb[-1]]
             else:
                 base = torch.arange(M).unsqueeze(0).repeat(M, 1)
                 allidx = base[base != torch.arange(M).unsqueeze(1)].view(M, M - 1)[s:e]
                 inb = k[allidx]
+                rec_inb.append(allidx)
                 short = num_inb - inb.shape[1]
                 if short > 0:
                     if item_table is not None:
                         rid = torch.randint(1, item_table.shape[0], (n, short))
                         re_ = item_table[rid]
                         inb = torch.cat([inb, F.normalize(re_, dim=-1) if normalize else re_], dim=1)
+                        rec_hard[-1].append(rid)
                     else:
                         inb = torch.cat([inb, inb[:, -1:].expand(-1, short, -1)], dim=1)
+                        rec_inb[-1] = torch.cat([allidx, allidx[:, -1:].expand(-1, short)], dim=1)
             negs.append(inb)
         keys = torch.cat([k[s:e].unsqueeze(1)] + negs, dim=1)
         logits = (q[s:e].unsqueeze(1) * keys).sum(-1) / temperature
         losses.append(-F.log_softmax(logits, dim=1)[:, 0])
+    if record is not None:
+        hard_parts = [torch.cat(h, dim=1) for h in rec_hard if h]
+        record['hard'] = torch.cat(hard_parts, dim=0) if hard_parts else None
+        record['inb'] = torch.cat(rec_inb, dim=0) if rec_inb else None
     return torch.cat(losses).mean()
 
 

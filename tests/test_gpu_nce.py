@@ -1,0 +1,123 @@
+"""Fused InfoNCE op (C ABI hmx_nce_fwd_f32 / hmx_nce_bwd_f32) against the oracle's index form of
+hydra3.py:845-974 on the same indices.  Tolerances: row losses 3e-5 absolute (values are 5..20), gradients
+2e-4 of the tensor's largest magnitude (fp32 sums in a different association order)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(M, d, R, n_hard, n_inb, seed, users=None, zero_rows=False):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(M, d, generator=g)
+    k = torch.randn(M, d, generator=g)
+    table = torch.randn(R, d, generator=g) * 0.3
+    table[0] = 0
+    hard = None
+    if n_hard:
+        if users:   # every user's positions share one list of 50 ids, tiled to n_hard (the train-step pattern)
+            per_user = torch.randint(1, R, (users, 50), generator=g)
+            owner = torch.sort(torch.randint(0, users, (M,), generator=g)).values
+            hard = per_user[owner].repeat(1, (n_hard + 49) // 50)[:, :n_hard].contiguous()
+        else:
+            hard = torch.randint(0, R, (M, n_hard), generator=g)
+    inb = None
+    if n_inb:
+        r = torch.randint(0, M - 1, (M, n_inb), generator=g)
+        inb = r + (r >= torch.arange(M).unsqueeze(1)).long()
+    if zero_rows:
+        q[3] = 0
+        k[5] = 0
+        if hard is not None:
+            hard[0, 0] = 0
+            hard[7, :4] = 0
+    return q, k, table, hard, inb
+
+
+def _check(q, k, table, hard, inb, temperature=0.05, normalize=True):
+    from oracle import hydra_oracle as O
+    from generative_recommenders_amd import ops
+    w = torch.randn(q.shape[0], generator=torch.Generator().manual_seed(1))     # non-uniform upstream gradient
+    cq, ck, ct = (t.clone().requires_grad_(True) for t in (q, k, table))
+    want = O.nce_rows(cq, ck, ct, hard, inb, temperature, normalize)
+    (want * w).sum().backward()
+    dev = "cuda"
+    gq, gk, gt = (t.to(dev).requires_grad_(True) for t in (q, k, table))
+    got = ops.fused_nce_rows(gq, gk, gt, None if hard is None else hard.to(dev), None if inb is None else inb.to(dev),
+                             temperature, normalize)
+    (got * w.to(dev)).sum().backward()
+    assert torch.allclose(got.detach().cpu(), want.detach(), atol=3e-5, rtol=1e-5), \
+        float((got.detach().cpu() - want.detach()).abs().max())
+    for name, a, b in (("dq", gq.grad, cq.grad), ("dk", gk.grad, ck.grad), ("dtable", gt.grad, ct.grad)):
+        if b is None or (name == "dtable" and hard is None):
+            continue
+        a = a.cpu()
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (name, float((a - b).abs().max()), scale)
+        touched_want = (b.abs().sum(1) > 0)
+        assert bool(((a.abs().sum(1) > 0) == touched_want).all()) or name != "dtable"
+
+
+@pytest.mark.parametrize("M,d,R,n_hard,n_inb", [
+    (300, 64, 5000, 153, 359),      # the train-step geometry
+    (37, 16, 200, 153, 20),
+    (64, 128, 1000, 10, 30),
+    (50, 8, 100, 7, 5),
+    (33, 256, 300, 20, 12),
+])
+def test_matches_oracle(M, d, R, n_hard, n_inb):
+    _check(*_case(M, d, R, n_hard, n_inb, seed=M))
+
+
+def test_user_structured_hard_negatives():
+    _check(*_case(900, 64, 20000, 153, 359, seed=3, users=12))
+
+
+def test_no_hard_or_no_inbatch():
+    _check(*_case(80, 64, 100, 0, 40, seed=5))
+    _check(*_case(80, 64, 100, 30, 0, seed=6))
+
+
+def test_without_normalisation_and_other_temperature():
+    q, k, table, hard, inb = _case(70, 32, 300, 15, 25, seed=8)
+    _check(q * 0.2, k * 0.2, table, hard, inb, temperature=0.5, normalize=False)
+    _check(q, k, table, hard, inb, temperature=1.0, normalize=True)
+
+
+def test_zero_rows_and_padding_row_as_negative():
+    q, k, table, hard, inb = _case(60, 64, 400, 20, 30, seed=9, zero_rows=True)
+    from oracle import hydra_oracle as O
+    from generative_recommenders_amd import ops
+    want = O.nce_rows(q, k, table, hard, inb)
+    got = ops.fused_nce_rows(q.cuda(), k.cuda(), table.cuda(), hard.cuda(), inb.cuda())
+    assert torch.allclose(got.cpu(), want, atol=3e-5, rtol=1e-5)
+
+
+def test_out_of_range_ids_are_zero_keys():
+    from oracle import hydra_oracle as O
+    from generative_recommenders_amd import ops
+    q, k, table, hard, inb = _case(40, 64, 300, 12, 10, seed=11)
+    bad = hard.clone()
+    bad[2, 3], bad[9, 0] = 300, -4
+    ext = torch.cat([table, torch.zeros(1, 64)])          # oracle view: a zero row stands in for the bad ids
+    ref_ids = bad.clone()
+    ref_ids[(bad < 0) | (bad >= 300)] = 300
+    want = O.nce_rows(q, k, ext, ref_ids, inb)
+    got = ops.fused_nce_rows(q.cuda(), k.cuda(), table.cuda(), bad.cuda(), inb.cuda())
+    assert torch.allclose(got.cpu(), want, atol=3e-5, rtol=1e-5)
+
+
+def test_loss_function_matches_oracle_on_exhaustive_batch():
+    """M - 1 < num_inb: the in-batch part is exhaustive and the shortfall comes from random table rows; with the
+    hard-negative lists shorter than num_hard nothing else is random, so only the fill differs between the two
+    RNGs -- compare with the fill disabled (no item table -> last in-batch key repeated)."""
+    from oracle import hydra_oracle as O
+    from generative_recommenders_amd import hydra as H
+    g = torch.Generator().manual_seed(2)
+    B, L, d = 5, 12, 64
+    lf, pe = torch.randn(B, L, d, generator=g), torch.randn(B, L, d, generator=g)
+    mask = torch.rand(B, L, generator=g) > 0.2
+    want = O.compute_mixed_contrastive_loss(lf, pe, mask, None, None)
+    got = H.compute_mixed_contrastive_loss(lf.cuda(), pe.cuda(), mask.cuda(), None, None)
+    assert abs(float(got) - float(want)) < 1e-4
