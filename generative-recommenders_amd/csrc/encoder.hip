@@ -248,7 +248,23 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgradParams p) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool n_ok = n < p.N;
     const int kind = kc < p.K ? 0 : ((kc == p.K && p.with_bias) ? 1 : 2);
-    for (int64_t t = t0; t < t1; t += 2) {
+    int64_t t = t0;
+    for (; t + 8 <= t1; t += 8) {   // four MFMA steps per trip, their eight loads issued together
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t tt = t + 2 * u + h;
+            a[u] = n_ok ? p.dY[tt * p.ldy + n] : 0.f;
+            b[u] = kind == 1 ? 1.f : 0.f;
+            if (kind == 0) {
+                b[u] = p.X[tt * p.ldx + kc];
+                if (p.in_rowmask) b[u] *= p.in_rowmask[tt];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; t < t1; t += 2) {
         const int64_t tt = t + h;
         const bool ok = tt < t1;
         const float a = (ok && n_ok) ? p.dY[tt * p.ldy + n] : 0.f;
@@ -737,10 +753,17 @@ extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64
     return HMX_OK;
 }
 
-static int64_t wgrad_splits(int64_t T) { return std::max<int64_t>(1, std::min<int64_t>(64, hmx_ceil_div(T, 256))); }
+// Token splits of the weight-gradient product: one wave per (split, 32x32 output tile).  Enough splits to put
+// about 2048 waves on the chip (the loop per wave is a dependent load -> MFMA chain), at least 128 tokens each.
+static int64_t wgrad_splits(int64_t T, int64_t N, int64_t K) {
+    const int64_t tiles = hmx_ceil_div(N, 32) * hmx_ceil_div(K + 1, 32);
+    int64_t s = hmx_ceil_div(2048, tiles);
+    s = std::min<int64_t>(s, hmx_ceil_div(T, 128));
+    return std::max<int64_t>(1, std::min<int64_t>(s, 512));
+}
 
 extern "C" size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K) {
-    return (size_t)wgrad_splits(T) * N * (K + 1) * sizeof(float) + 256;
+    return (size_t)wgrad_splits(T, N, K) * N * (K + 1) * sizeof(float) + 256;
 }
 
 extern "C" int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, const float* in_rowmask,
@@ -750,7 +773,7 @@ extern "C" int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X
     if (N == 0 || K == 0) return HMX_OK;
     if (!dY || !X || !dW || !workspace || T <= 0) return HMX_EINVAL;
     if (workspace_bytes < hmx_linear_wgrad_workspace_bytes(T, N, K)) return HMX_EWORKSPACE;
-    const int64_t S = wgrad_splits(T);
+    const int64_t S = wgrad_splits(T, N, K);
     const int with_bias = dbias != nullptr;
     const int kx = (int)K + with_bias;
     int64_t tps = hmx_ceil_div(T, S);

@@ -109,7 +109,7 @@ extern "C" int hmx_gather_routed_f32(const float* item_table, int64_t item_rows,
 }
 
 extern "C" size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows, int64_t d) {
-    return hmx_seg::workspace_bytes(n, n_rows, d);
+    return hmx_seg::workspace_bytes<hmx_seg::PlainRows>(n, n_rows, d);
 }
 
 extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,

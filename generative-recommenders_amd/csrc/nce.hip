@@ -416,8 +416,8 @@ extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_
 
 extern "C" size_t hmx_nce_bwd_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb) {
     if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb)) return 256;
-    size_t a = n_inb > 0 ? hmx_seg::workspace_bytes(m * n_inb, m, d) : 256;
-    size_t b = n_hard > 0 ? hmx_seg::workspace_bytes(m * n_hard, n_rows, d) : 256;
+    size_t a = n_inb > 0 ? hmx_seg::workspace_bytes<WeightedRows>(m * n_inb, m, d) : 256;
+    size_t b = n_hard > 0 ? hmx_seg::workspace_bytes<WeightedRows>(m * n_hard, n_rows, d) : 256;
     return a > b ? a : b;
 }
 

@@ -37,9 +37,14 @@ __device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
 
 // value(entry) = rows[entry]: the plain scatter-add of materialised gradient rows
 struct PlainRows {
+    using Val = uint32_t;               // what travels with the key through the sort: the entry number
+    static constexpr int kInFlight = 4; // entries summed per trip of the run loop
+    static constexpr int kPiece = 512;  // the sorted array is also cut every kPiece entries
+    static constexpr bool kBalanced = false;   // one group per run start (summation order fixed by the contract)
     const float* rows;
+    __device__ __forceinline__ Val make_val(int64_t e) const { return (uint32_t)e; }
     template <int VEC>
-    __device__ __forceinline__ typename VecT<VEC>::type load(uint32_t pos, int cpr, int c) const {
+    __device__ __forceinline__ typename VecT<VEC>::type load(Val pos, int cpr, int c) const {
         return reinterpret_cast<const typename VecT<VEC>::type*>(rows)[(int64_t)pos * cpr + c];
     }
 };
@@ -50,14 +55,23 @@ __device__ __forceinline__ float vscale(float a, const float& v) { return a * v;
 // value(entry) = coef[i, col0 + s] * rows[i] with entry = i * per_row + s: the transposed product of a sparse
 // coefficient matrix with a dense row matrix, never materialised
 struct WeightedRows {
+    // The coefficient rides through the sort next to the source row number, so the run loop reads it from the
+    // sorted stream instead of chasing a random 4-byte load per entry.
+    using Val = uint2;                  // (source row i, coefficient bits)
+    static constexpr int kInFlight = 8;
+    static constexpr int kPiece = 128;
+    static constexpr bool kBalanced = true;    // one group per block of kPiece entries (runs here are long)
     const float* rows;      // (n_src, d)
     const float* coef;      // (n_src, coef_stride)
     int per_row, coef_stride, col0;
+    __device__ __forceinline__ Val make_val(int64_t e) const {
+        const int64_t i = e / per_row, sidx = e - i * per_row;
+        return make_uint2((uint32_t)i, __float_as_uint(coef[i * coef_stride + col0 + sidx]));
+    }
     template <int VEC>
-    __device__ __forceinline__ typename VecT<VEC>::type load(uint32_t pos, int cpr, int c) const {
-        const uint32_t i = pos / (uint32_t)per_row, sidx = pos - i * (uint32_t)per_row;
-        const float a = coef[(int64_t)i * coef_stride + col0 + sidx];
-        return vscale(a, reinterpret_cast<const typename VecT<VEC>::type*>(rows)[(int64_t)i * cpr + c]);
+    __device__ __forceinline__ typename VecT<VEC>::type load(Val v, int cpr, int c) const {
+        return vscale(__uint_as_float(v.y),
+                      reinterpret_cast<const typename VecT<VEC>::type*>(rows)[(int64_t)v.x * cpr + c]);
     }
 };
 
@@ -69,17 +83,18 @@ inline int lpr_log2_for(int64_t cpr) {
 
 // ---------------------------------------------------------------- scatter-add ----------
 // Step 1: sort key = row id (or `sentinel` for entries that must not contribute), value = i.
-__global__ __launch_bounds__(kBlock) void make_keys_kernel(const int64_t* __restrict__ ids,
+template <class Src>
+__global__ __launch_bounds__(kBlock) void make_keys_kernel(Src src, const int64_t* __restrict__ ids,
                                                            const int64_t* __restrict__ token_type, int64_t want_type,
                                                            int64_t n, int64_t n_rows, int64_t padding_idx,
                                                            uint32_t sentinel, uint32_t* __restrict__ keys,
-                                                           uint32_t* __restrict__ vals) {
+                                                           typename Src::Val* __restrict__ vals) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const int64_t id = ids[i];
         bool ok = id >= 0 && id < n_rows && id != padding_idx;
         if (token_type != nullptr) ok = ok && token_type[i] == want_type;
         keys[i] = ok ? (uint32_t)id : sentinel;
-        vals[i] = (uint32_t)i;
+        vals[i] = src.make_val(i);
     }
 }
 
@@ -99,7 +114,7 @@ constexpr int kSuper = 512;
 template <int VEC, class Src>
 __global__ __launch_bounds__(kBlock) void segment_sum_kernel(Src src,
                                                              const uint32_t* __restrict__ skeys,
-                                                             const uint32_t* __restrict__ svals, int64_t n, int cpr,
+                                                             const typename Src::Val* __restrict__ svals, int64_t n, int cpr,
                                                              int lpr_log2, uint32_t sentinel,
                                                              float* __restrict__ grad_table,
                                                              float* __restrict__ head_piece,
@@ -128,26 +143,31 @@ __global__ __launch_bounds__(kBlock) void segment_sum_kernel(Src src,
             for (int c = lane_c; c < cpr; c += lpr) {
                 V acc = vzero<VEC>();
                 int64_t e = j;
+                constexpr int U = Src::kInFlight;
                 while (true) {
-                    bool m[4];
-                    V v[4];
+                    bool m[U];
+                    typename Src::Val sv[U];
+                    V v[U];
                     bool run = true;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < U; ++u) {
                         run = run && (e + u < blk_end) && (skeys[e + u] == key);
                         m[u] = run;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        v[u] = m[u] ? src.template load<VEC>(svals[e + u], cpr, c) : vzero<VEC>();
+                    for (int u = 0; u < U; ++u)
+                        if (m[u]) sv[u] = svals[e + u];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < U; ++u)
+                        v[u] = m[u] ? src.template load<VEC>(sv[u], cpr, c) : vzero<VEC>();
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
                         if (m[u]) {
                             vadd(acc, v[u]);
                             e_end = e + u + 1;
                         }
-                    if (!m[3]) break;
-                    e += 4;
+                    if (!m[U - 1]) break;
+                    e += U;
                 }
                 {
                     const bool ends_true = (e_end == n) || skeys[e_end] != key;
@@ -176,33 +196,118 @@ __global__ __launch_bounds__(kBlock) void segment_sum_kernel(Src src,
     }
 }
 
-// Pass 2: one group per super-block b; acts only if a run starts inside b and continues past its end.
-template <int VEC>
+// Pass 1, balanced form: one group walks one block of SB consecutive sorted entries, whatever runs it holds, so
+// every group has the same amount of work and long runs are summed by many groups at once.  Partial sums of runs
+// that cross a block boundary go to head_piece / tail_piece exactly as in segment_sum_kernel (with kSuper = SB);
+// runs that lie inside one block are added to their row directly (one writer per row).
+template <int VEC, class Src, int SB>
+__global__ __launch_bounds__(kBlock) void segment_sum_balanced_kernel(Src src, const uint32_t* __restrict__ skeys,
+                                                                      const typename Src::Val* __restrict__ svals,
+                                                                      int64_t n, int cpr, int lpr_log2,
+                                                                      uint32_t sentinel, float* __restrict__ grad_table,
+                                                                      float* __restrict__ head_piece,
+                                                                      float* __restrict__ tail_piece) {
+    using V = typename VecT<VEC>::type;
+    constexpr int U = Src::kInFlight;
+    static_assert(SB % U == 0, "block size must be a multiple of the prefetch depth");
+    const int lpr = 1 << lpr_log2;
+    const int lane_c = threadIdx.x & (lpr - 1);
+    const int groups_per_block = kBlock >> lpr_log2;
+    const int64_t n_sb = (n + SB - 1) / SB;
+    for (int64_t b = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> lpr_log2); b < n_sb;
+         b += (int64_t)gridDim.x * groups_per_block) {
+        const int64_t j0 = b * SB;
+        const int64_t j1 = (j0 + SB < n) ? j0 + SB : n;
+        const uint32_t key_before = (j0 > 0) ? skeys[j0 - 1] : sentinel;
+        const uint32_t key_after = (j1 < n) ? skeys[j1] : sentinel;
+        for (int c = lane_c; c < cpr; c += lpr) {
+            V acc = vzero<VEC>();
+            uint32_t cur = skeys[j0];
+            bool first_run = true;   // the run being summed began at j0 (it may continue an older block's run)
+            auto flush = [&](bool ends_here) {
+                if (cur == sentinel) return;
+                const bool starts_true = !(first_run && cur == key_before);
+                V* dst;
+                if (starts_true && ends_here) {
+                    dst = reinterpret_cast<V*>(grad_table) + (int64_t)cur * cpr + c;
+                    V t = *dst;
+                    vadd(t, acc);
+                    *dst = t;
+                } else if (!starts_true) {
+                    reinterpret_cast<V*>(head_piece)[b * cpr + c] = acc;
+                } else {
+                    reinterpret_cast<V*>(tail_piece)[b * cpr + c] = acc;
+                }
+            };
+            for (int64_t e = j0; e < j1; e += U) {
+                uint32_t key[U];
+                typename Src::Val sv[U];
+                V v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) key[u] = (e + u < j1) ? skeys[e + u] : sentinel;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (key[u] != sentinel) sv[u] = svals[e + u];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    v[u] = (key[u] != sentinel) ? src.template load<VEC>(sv[u], cpr, c) : vzero<VEC>();
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (e + u >= j1) break;
+                    if (key[u] != cur) {
+                        flush(true);
+                        acc = vzero<VEC>();
+                        cur = key[u];
+                        first_run = false;
+                    }
+                    if (key[u] != sentinel) vadd(acc, v[u]);
+                }
+            }
+            flush(cur != key_after);
+        }
+    }
+}
+
+// Pass 2: one group per block b of SB entries; acts only if a run starts inside b and continues past its end.
+template <int VEC, int SB>
 __global__ __launch_bounds__(kBlock) void segment_join_kernel(const uint32_t* __restrict__ skeys, int64_t n, int cpr,
                                                               int lpr_log2, uint32_t sentinel,
                                                               float* __restrict__ grad_table,
                                                               const float* __restrict__ head_piece,
                                                               const float* __restrict__ tail_piece) {
     using V = typename VecT<VEC>::type;
+    constexpr int U = 8;   // head pieces fetched per trip (their "does the run go on" keys with them)
     const int lpr = 1 << lpr_log2;
     const int lane_c = threadIdx.x & (lpr - 1);
     const int groups_per_block = kBlock >> lpr_log2;
-    const int64_t n_sb = (n + kSuper - 1) / kSuper;
+    const int64_t n_sb = (n + SB - 1) / SB;
     for (int64_t b = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> lpr_log2); b < n_sb;
          b += (int64_t)gridDim.x * groups_per_block) {
-        const int64_t end = (b + 1) * kSuper;
+        const int64_t end = (b + 1) * SB;
         if (end >= n) continue;                                   // last block: nothing continues
         const uint32_t key = skeys[end - 1];
         if (key == sentinel || skeys[end] != key) continue;       // no run crosses this boundary
-        if (skeys[b * kSuper] == key && b > 0 && skeys[b * kSuper - 1] == key) continue;  // run started earlier
+        if (skeys[b * SB] == key && b > 0 && skeys[b * SB - 1] == key) continue;  // run started earlier
         for (int c = lane_c; c < cpr; c += lpr) {
             V acc = reinterpret_cast<const V*>(tail_piece)[b * cpr + c];
-            int64_t cb = b + 1;
-            while (true) {
-                vadd(acc, reinterpret_cast<const V*>(head_piece)[cb * cpr + c]);
-                const int64_t cend = (cb + 1) * kSuper;
-                if (cend < n && skeys[cend - 1] == key && skeys[cend] == key) ++cb;
-                else break;
+            int64_t cb = b + 1;       // block cb is known to begin with this run
+            bool more = true;
+            while (more) {
+                V hp[U];
+                bool goes_on[U];      // the run also covers the start of block cb + u + 1
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t cend = (cb + u + 1) * SB;
+                    goes_on[u] = cend < n && skeys[cend - 1] == key && skeys[cend] == key;
+                    hp[u] = (cb + u < n_sb) ? reinterpret_cast<const V*>(head_piece)[(cb + u) * cpr + c] : vzero<VEC>();
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!more) break;
+                    vadd(acc, hp[u]);
+                    more = goes_on[u];
+                }
+                cb += U;
             }
             V* dst = reinterpret_cast<V*>(grad_table) + (int64_t)key * cpr + c;
             V cur = *dst;
@@ -218,23 +323,28 @@ inline int sort_bits(int64_t n_rows) {
     return b;
 }
 
+template <class Val>
 inline size_t rocprim_sort_temp_bytes(int64_t n, int bits) {
     size_t bytes = 0;
     uint32_t* p = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)n, 0u, (unsigned)bits, hipStreamDefault);
+    Val* v = nullptr;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, p, p, v, v, (size_t)n, 0u, (unsigned)bits, hipStreamDefault);
     if (e != hipSuccess) return 0;
     return bytes;
 }
 
 
-inline size_t piece_bytes(int64_t n, int64_t d) {
-    return hmx_align_up((size_t)hmx_ceil_div(n, kSuper) * (size_t)d * sizeof(float), 256);
+inline size_t piece_bytes(int64_t n, int64_t d, int piece) {
+    return hmx_align_up((size_t)hmx_ceil_div(n, piece) * (size_t)d * sizeof(float), 256);
 }
 
+template <class Src>
 inline size_t workspace_bytes(int64_t n, int64_t n_rows, int64_t d) {
     if (n <= 0 || n_rows <= 0 || d <= 0) return 256;
-    const size_t arr = hmx_align_up((size_t)n * sizeof(uint32_t), 256);
-    return 4 * arr + 2 * piece_bytes(n, d) + hmx_align_up(rocprim_sort_temp_bytes(n, sort_bits(n_rows)), 256) + 256;
+    const size_t karr = hmx_align_up((size_t)n * sizeof(uint32_t), 256);
+    const size_t varr = hmx_align_up((size_t)n * sizeof(typename Src::Val), 256);
+    return 2 * karr + 2 * varr + 2 * piece_bytes(n, d, Src::kPiece) +
+           hmx_align_up(rocprim_sort_temp_bytes<typename Src::Val>(n, sort_bits(n_rows)), 256) + 256;
 }
 
 // table[ids[e]] += value(e) for e in [0, n).  `vec`: rows and table are 16-byte aligned and d % 4 == 0.
@@ -246,24 +356,24 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
                        size_t ws_bytes, hipStream_t s, const uint32_t** sorted_keys_out = nullptr,
                        uint32_t* sentinel_out = nullptr) {
     const int bits = sort_bits(n_rows);
-    size_t temp_bytes = rocprim_sort_temp_bytes(n, bits);
-    const size_t arr = hmx_align_up((size_t)n * sizeof(uint32_t), 256);
-    if (ws_bytes < 4 * arr + 2 * piece_bytes(n, d) + hmx_align_up(temp_bytes, 256)) return HMX_EWORKSPACE;
+    using Val = typename Src::Val;
+    size_t temp_bytes = rocprim_sort_temp_bytes<Val>(n, bits);
+    if (ws_bytes < workspace_bytes<Src>(n, n_rows, d) - 256) return HMX_EWORKSPACE;
     HmxCarver ws(workspace);
     uint32_t* keys = ws.take<uint32_t>(n);
-    uint32_t* vals = ws.take<uint32_t>(n);
+    Val* vals = ws.take<Val>(n);
     uint32_t* skeys = ws.take<uint32_t>(n);
-    uint32_t* svals = ws.take<uint32_t>(n);
-    float* head_piece = ws.take<float>(piece_bytes(n, d) / sizeof(float));
-    float* tail_piece = ws.take<float>(piece_bytes(n, d) / sizeof(float));
+    Val* svals = ws.take<Val>(n);
+    float* head_piece = ws.take<float>(piece_bytes(n, d, Src::kPiece) / sizeof(float));
+    float* tail_piece = ws.take<float>(piece_bytes(n, d, Src::kPiece) / sizeof(float));
     void* temp = ws.take<char>(temp_bytes);
     const uint32_t sentinel = (uint32_t)n_rows;
     if (sorted_keys_out) *sorted_keys_out = skeys;
     if (sentinel_out) *sentinel_out = sentinel;
 
     const int grid1 = (int)std::min<int64_t>(hmx_ceil_div(n, kBlock), kMaxGrid);
-    hipLaunchKernelGGL(make_keys_kernel, dim3(grid1), dim3(kBlock), 0, s, ids, token_type, want_type, n, n_rows,
-                       padding_idx, sentinel, keys, vals);
+    hipLaunchKernelGGL(make_keys_kernel<Src>, dim3(grid1), dim3(kBlock), 0, s, src, ids, token_type, want_type, n,
+                       n_rows, padding_idx, sentinel, keys, vals);
     HMX_CHECK_LAUNCH();
     if (rocprim::radix_sort_pairs(temp, temp_bytes, keys, skeys, vals, svals, (size_t)n, 0u, (unsigned)bits, s) !=
         hipSuccess)
@@ -271,20 +381,29 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
 
     const int64_t cpr = vec ? d / 4 : d;
     const int l2 = lpr_log2_for(cpr);
-    const int64_t groups = hmx_ceil_div(n, kChunk);
+    constexpr int SB = Src::kPiece;
+    const int64_t n_sb = hmx_ceil_div(n, SB);
+    const int64_t groups = Src::kBalanced ? n_sb : hmx_ceil_div(n, kChunk);
     const int grid3 = (int)std::min<int64_t>(hmx_ceil_div(groups, kBlock >> l2), (int64_t)kMaxGrid * 4);
-    const int64_t n_sb = hmx_ceil_div(n, kSuper);
     const int grid4 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid);
     if (vec) {
-        hipLaunchKernelGGL((segment_sum_kernel<4, Src>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals, n, (int)cpr,
-                           l2, sentinel, table, head_piece, tail_piece);
-        hipLaunchKernelGGL(segment_join_kernel<4>, dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2, sentinel,
-                           table, head_piece, tail_piece);
+        if constexpr (Src::kBalanced)
+            hipLaunchKernelGGL((segment_sum_balanced_kernel<4, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys,
+                               svals, n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+        else
+            hipLaunchKernelGGL((segment_sum_kernel<4, Src>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals, n,
+                               (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+        hipLaunchKernelGGL((segment_join_kernel<4, SB>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
+                           sentinel, table, head_piece, tail_piece);
     } else {
-        hipLaunchKernelGGL((segment_sum_kernel<1, Src>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals, n, (int)cpr,
-                           l2, sentinel, table, head_piece, tail_piece);
-        hipLaunchKernelGGL(segment_join_kernel<1>, dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2, sentinel,
-                           table, head_piece, tail_piece);
+        if constexpr (Src::kBalanced)
+            hipLaunchKernelGGL((segment_sum_balanced_kernel<1, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys,
+                               svals, n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+        else
+            hipLaunchKernelGGL((segment_sum_kernel<1, Src>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals, n,
+                               (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+        hipLaunchKernelGGL((segment_join_kernel<1, SB>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
+                           sentinel, table, head_piece, tail_piece);
     }
     HMX_CHECK_LAUNCH();
     return HMX_OK;
