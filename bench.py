@@ -164,6 +164,16 @@ def main():
         out = run_train(args, world, rank)
     else:
         out = run_retrieval(args, world, rank)
+        if args.workload == "auto" and world == 1:
+            # BASELINE.json's metric has two halves; the line's value / scaling series is the retrieval half
+            # (the one quoted at 1/2/4/8 GPUs), the single-GPU train step (configs[1]) rides along here.
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            from bench_train import run_train
+            t = run_train(args, world, rank)
+            out["train_step"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "fwd_bwd_ms", "config",
+                                                   "roofline", "other_kernels", "cpu_baseline", "loss") if k in t}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

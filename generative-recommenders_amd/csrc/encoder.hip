@@ -288,17 +288,28 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgradParams p) {
     }
 }
 
-// dW[n * ldw + k] = sum_s part[s][n][k];  db[n] = sum_s part[s][n][K]
+// dW[n * ldw + k] = sum_s part[s][n][k];  db[n] = sum_s part[s][n][K].
+// Block = 16 outputs x 16 split lanes: lane g sums splits g, g + 16, ... in order, then the 16 partial sums are
+// added in lane order (fixed association, so the result does not depend on timing).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int n_splits, int N, int K,
                                                            int kx, float* __restrict__ dW, int64_t ldw,
                                                            float* __restrict__ db) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= N * kx) return;
-    const int n = idx / kx, k = idx % kx;
+    __shared__ float sh[16][17];
+    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + o;
     float s = 0.f;
-    for (int sp = 0; sp < n_splits; ++sp) s += part[((int64_t)sp * N + n) * kx + k];
-    if (k < K) dW[(int64_t)n * ldw + k] = s;
-    else if (db) db[n] = s;
+    if (idx < N * kx)
+        for (int sp = g; sp < n_splits; sp += 16) s += part[(int64_t)sp * N * kx + idx];
+    sh[g][o] = s;
+    __syncthreads();
+    if (g == 0 && idx < N * kx) {
+        float t = sh[0][o];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t += sh[j][o];
+        const int n = idx / kx, k = idx % kx;
+        if (k < K) dW[(int64_t)n * ldw + k] = t;
+        else if (db) db[n] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------- pointwise kernels
@@ -783,7 +794,7 @@ extern "C" int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)S, (unsigned)(hmx_ceil_div(N, 32) * hmx_ceil_div(kx, 32))), dim3(64), 0,
                        s, p);
     HMX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)hmx_ceil_div(N * kx, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)hmx_ceil_div(N * kx, 16)), dim3(256), 0, s,
                        (const float*)workspace, (int)S, (int)N, (int)K, kx, dW, ldw, dbias);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
