@@ -49,6 +49,7 @@ struct CoarseParams {
     const int64_t* exclude;   // (n_q, n_excl) global ids or null
     int n_excl;
     int64_t id_offset;
+    const float* init_thr;    // (n_q_pad) starting threshold per query or null (-inf)   [bf16 pass]
     uint2* cand;              // [wave][g][lane][CAP] (score bits, local row)
     int* meta_cnt;            // [wave][g][lane]
     float* meta_thr;          // [wave][g][lane]
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
     int cnt[NB];
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
-        thr[g] = kNegInf;
+        thr[g] = p.init_thr ? p.init_thr[(int64_t)qtile * 32 * NB + 32 * g + j] : kNegInf;
         cnt[g] = 0;
     }
     const int n_rows_here = (int)max(row_end - row_begin, (int64_t)0);
@@ -557,6 +558,34 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const int64_t* __restric
     }
 }
 
+// Starting thresholds for the full pass from the exact top-K of a sample of the rows (scores (n_q, k), best
+// first).  K rows of the sample score at least t = scores[q][k-1] exactly, so the K-th best exact score over ALL
+// rows is >= t, and every row of the final top-K has a coarse score >= t - eps (eps = bound of the bf16 coarse
+// error).  The threshold sits a hair below t - eps so that the completeness proof of the re-score kernel
+// (K-th exact score > largest threshold + eps) still holds when no list ever raised its threshold further.
+// Queries beyond n_q (padding of the last tile) get +inf: they never append.
+__global__ __launch_bounds__(256) void seed_threshold_kernel(const float* __restrict__ scores, const float* __restrict__ q,
+                                                             int64_t n_q, int64_t n_q_pad, int d, int k,
+                                                             const float* __restrict__ max_row_norm,
+                                                             float* __restrict__ init_thr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_q_pad) return;
+    if (i >= n_q) {
+        init_thr[i] = INFINITY;
+        return;
+    }
+    const float t = scores[i * k + k - 1];
+    if (!(t > kNegInf)) {           // fewer than k sample rows survived the exclusions
+        init_thr[i] = kNegInf;
+        return;
+    }
+    float n2 = 0.f;
+    for (int c = 0; c < d; ++c) n2 = __builtin_fmaf(q[i * d + c], q[i * d + c], n2);
+    const float eps = 0.00398f * sqrtf(n2) * max_row_norm[0];
+    const float lo = t - eps;
+    init_thr[i] = lo - fmaxf(fabsf(lo), eps) * 1e-5f - 1e-30f;
+}
+
 // ------------------------------------------------------------------ host-side planning
 struct Plan {
     int NB, KP, KS, dpad;
@@ -564,8 +593,8 @@ struct Plan {
     int n_qtiles;        // per full chunk
     int n_splits;
     int64_t rows_per_split;
-    size_t q_bf16_bytes, cand_bytes, meta_bytes;
-    size_t total() const { return q_bf16_bytes + cand_bytes + 2 * meta_bytes + 1024; }
+    size_t q_bf16_bytes, cand_bytes, meta_bytes, thr_bytes;
+    size_t total() const { return q_bf16_bytes + cand_bytes + 2 * meta_bytes + thr_bytes + 1280; }
 };
 
 int dpad_for(int64_t d) {
@@ -596,6 +625,7 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
     pl.q_bf16_bytes = bf16 ? hmx_align_up((size_t)pl.chunk * pl.dpad * 2, 256) : 0;
     pl.cand_bytes = hmx_align_up((size_t)waves * pl.NB * 64 * cap_for(pl.KP) * sizeof(uint2), 256);
     pl.meta_bytes = hmx_align_up((size_t)waves * pl.NB * 64 * 4, 256);
+    pl.thr_bytes = bf16 ? hmx_align_up((size_t)pl.chunk * sizeof(float), 256) : 0;
     return true;
 }
 
@@ -634,92 +664,159 @@ void launch_rescore(const RescoreParams& r, hipStream_t s) {
 #undef HMX_RS
 }
 
+// Threshold seeding for the bf16 pass.  A pass that starts with thresholds at -inf spends its first tiles
+// appending every score and compacting every list; so the table prefixes of 256, 4096 and 65536 rows are scored
+// first, each seeded with the exact top-K of the one before.  Only the 256-row pass starts cold; every later pass
+// sees about K * (growth factor) scores above its starting thresholds per query.
+constexpr int kMaxSeedLevels = 3;
+int seed_levels(int64_t n_rows, int64_t* sample_rows) {
+    int n = 0;
+    for (int64_t r = 256; r <= 65536 && r * 8 <= n_rows; r *= 16) sample_rows[n++] = r;
+    return n;
+}
+
+struct TopkPlans {
+    Plan full;
+    Plan seed[kMaxSeedLevels];
+    int64_t seed_rows[kMaxSeedLevels];
+    int n_seed;
+    size_t cand_bytes, meta_bytes;
+    size_t total() const { return full.q_bf16_bytes + full.thr_bytes + cand_bytes + 2 * meta_bytes + 1536; }
+};
+
+bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, TopkPlans& tp) {
+    if (!make_plan(n_q, n_rows, d, k, bf16, tp.full)) return false;
+    tp.n_seed = 0;
+    tp.cand_bytes = tp.full.cand_bytes;
+    tp.meta_bytes = tp.full.meta_bytes;
+    if (!bf16) return true;
+    // Seeding pays when every wave of the full pass covers only a slice of the table (few queries, many item
+    // splits): there the cold start is most of a wave's life.  With >= 64 K queries per launch each wave walks
+    // the whole table and the extra re-score passes cost more than the cold start they remove.
+    int64_t rows[kMaxSeedLevels];
+    const int n = tp.full.n_splits >= 8 ? seed_levels(n_rows, rows) : 0;
+    for (int i = 0; i < n; ++i) {
+        Plan ps;
+        if (!make_plan(n_q, rows[i], d, k, true, ps) || ps.chunk != tp.full.chunk) {
+            tp.n_seed = 0;
+            tp.cand_bytes = tp.full.cand_bytes;
+            tp.meta_bytes = tp.full.meta_bytes;
+            return true;
+        }
+        tp.seed[i] = ps;
+        tp.seed_rows[i] = rows[i];
+        tp.n_seed = i + 1;
+        tp.cand_bytes = std::max(tp.cand_bytes, ps.cand_bytes);
+        tp.meta_bytes = std::max(tp.meta_bytes, ps.meta_bytes);
+    }
+    return true;
+}
+
 int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, const uint16_t* table_bf16,
              const float* max_row_norm, int64_t n_rows, int64_t d, int64_t k, const int64_t* exclude, int64_t n_excl,
              int64_t id_offset, int64_t* out_ids, float* out_scores, int32_t* uncertain, void* workspace,
              size_t workspace_bytes, hipStream_t s) {
     if (n_q == 0) return HMX_OK;
-    Plan pl;
-    if (!make_plan(n_q, n_rows, d, k, bf16, pl)) return HMX_EINVAL;
+    TopkPlans tp;
+    if (!make_plans(n_q, n_rows, d, k, bf16, tp)) return HMX_EINVAL;
+    const Plan& pl = tp.full;
     if (!queries || !table || !out_ids || !out_scores || !workspace) return HMX_EINVAL;
     if (bf16 && (!table_bf16 || !max_row_norm || !uncertain)) return HMX_EINVAL;
     if (exclude == nullptr) n_excl = 0;
-    if (workspace_bytes < pl.total()) return HMX_EWORKSPACE;
+    if (workspace_bytes < tp.total()) return HMX_EWORKSPACE;
     HmxCarver ws(workspace);
     uint16_t* q_bf16 = bf16 ? ws.take<uint16_t>((size_t)pl.chunk * pl.dpad) : nullptr;
-    uint2* cand = ws.take<uint2>(pl.cand_bytes / sizeof(uint2));
-    int* meta_cnt = ws.take<int>(pl.meta_bytes / 4);
-    float* meta_thr = ws.take<float>(pl.meta_bytes / 4);
+    float* init_thr = bf16 ? ws.take<float>((size_t)pl.chunk) : nullptr;
+    uint2* cand = ws.take<uint2>(tp.cand_bytes / sizeof(uint2));
+    int* meta_cnt = ws.take<int>(tp.meta_bytes / 4);
+    float* meta_thr = ws.take<float>(tp.meta_bytes / 4);
     const int64_t qpw = 32 * pl.NB;
+    const bool excl = exclude != nullptr && n_excl > 0;
 
     for (int64_t q0 = 0; q0 < n_q; q0 += pl.chunk) {
         const int64_t nq = std::min(pl.chunk, n_q - q0);
         const int n_qtiles = (int)hmx_ceil_div(nq, qpw);
-        const int waves = n_qtiles * pl.n_splits;
-        CoarseParams p{};
-        p.q_bf16 = q_bf16;
-        p.t_bf16 = table_bf16;
-        p.q_f32 = queries + q0 * d;
-        p.t_f32 = table;
-        p.n_q = nq;
-        p.n_rows = n_rows;
-        p.d = (int)d;
-        p.dpad = pl.dpad;
-        p.n_qtiles = n_qtiles;
-        p.n_splits = pl.n_splits;
-        p.rows_per_split = pl.rows_per_split;
-        p.exclude = exclude ? exclude + q0 * n_excl : nullptr;
-        p.n_excl = (int)n_excl;
-        p.id_offset = id_offset;
-        p.cand = cand;
-        p.meta_cnt = meta_cnt;
-        p.meta_thr = meta_thr;
-        const bool excl = exclude != nullptr && n_excl > 0;
-        void* span = nullptr;
-        if (bf16) {
-            const int64_t rows_pad = (int64_t)n_qtiles * qpw;
-            hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)std::min<int64_t>(hmx_ceil_div(rows_pad, 16), 8192)), dim3(256), 0, s,
-                               queries + q0 * d, nq, (int)d, rows_pad, pl.dpad, q_bf16, (unsigned*)nullptr);
-            span = hmx_profile_begin("topk_coarse_bf16", s);
-            if (pl.NB == 4) launch_bf16_ks<4>(p, pl.KS, pl.KP, s);
-            else if (pl.NB == 2) launch_bf16_ks<2>(p, pl.KS, pl.KP, s);
-            else launch_bf16_ks<1>(p, pl.KS, pl.KP, s);
-        } else {
-            span = hmx_profile_begin("topk_coarse_f32", s);
-            if (pl.KP == 32) {
+        const int64_t rows_pad = (int64_t)n_qtiles * qpw;
+        if (bf16)
+            hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)std::min<int64_t>(hmx_ceil_div(rows_pad, 16), 8192)),
+                               dim3(256), 0, s, queries + q0 * d, nq, (int)d, rows_pad, pl.dpad, q_bf16,
+                               (unsigned*)nullptr);
+        // one coarse pass + exact re-score over the first `rows` rows of the table
+        auto pass = [&](const Plan& plan, int64_t rows, const float* thr0, int32_t* flags, const char* tag) -> int {
+            const int waves = n_qtiles * plan.n_splits;
+            CoarseParams p{};
+            p.q_bf16 = q_bf16;
+            p.t_bf16 = table_bf16;
+            p.q_f32 = queries + q0 * d;
+            p.t_f32 = table;
+            p.n_q = nq;
+            p.n_rows = rows;
+            p.d = (int)d;
+            p.dpad = plan.dpad;
+            p.n_qtiles = n_qtiles;
+            p.n_splits = plan.n_splits;
+            p.rows_per_split = plan.rows_per_split;
+            p.exclude = exclude ? exclude + q0 * n_excl : nullptr;
+            p.n_excl = (int)n_excl;
+            p.id_offset = id_offset;
+            p.init_thr = thr0;
+            p.cand = cand;
+            p.meta_cnt = meta_cnt;
+            p.meta_thr = meta_thr;
+            void* span = hmx_profile_begin(tag, s);
+            if (bf16) {
+                if (plan.NB == 4) launch_bf16_ks<4>(p, plan.KS, plan.KP, s);
+                else if (plan.NB == 2) launch_bf16_ks<2>(p, plan.KS, plan.KP, s);
+                else launch_bf16_ks<1>(p, plan.KS, plan.KP, s);
+            } else if (plan.KP == 32) {
                 if (excl) hipLaunchKernelGGL((coarse_f32_kernel<32, true>), dim3(waves), dim3(64), 0, s, p);
                 else hipLaunchKernelGGL((coarse_f32_kernel<32, false>), dim3(waves), dim3(64), 0, s, p);
             } else {
                 if (excl) hipLaunchKernelGGL((coarse_f32_kernel<64, true>), dim3(waves), dim3(64), 0, s, p);
                 else hipLaunchKernelGGL((coarse_f32_kernel<64, false>), dim3(waves), dim3(64), 0, s, p);
             }
+            hmx_profile_end(span, s);
+            HMX_CHECK_LAUNCH();
+            RescoreParams r{};
+            r.q_f32 = queries + q0 * d;
+            r.t_f32 = table;
+            r.n_q = nq;
+            r.n_rows = rows;
+            r.d = (int)d;
+            r.NB = plan.NB;
+            r.KP = plan.KP;
+            r.cap = cap_for(plan.KP);
+            r.n_splits = plan.n_splits;
+            r.cand = cand;
+            r.meta_cnt = meta_cnt;
+            r.meta_thr = meta_thr;
+            r.k = (int)k;
+            r.id_offset = id_offset;
+            r.max_row_norm = bf16 ? max_row_norm : nullptr;
+            // bf16 pass: exclusions are applied here.  fp32 pass: the coarse kernel already skipped them.
+            r.exclude = (bf16 && excl) ? exclude + q0 * n_excl : nullptr;
+            r.n_excl = (int)n_excl;
+            r.out_ids = out_ids + q0 * k;
+            r.out_scores = out_scores + q0 * k;
+            r.uncertain = flags;
+            launch_rescore(r, s);
+            HMX_CHECK_LAUNCH();
+            return HMX_OK;
+        };
+        const float* thr0 = nullptr;
+        for (int lvl = 0; lvl < tp.n_seed; ++lvl) {
+            // exact top-K of the prefix lands in the output buffers (overwritten by the next pass)
+            const int rc = pass(tp.seed[lvl], tp.seed_rows[lvl], thr0, nullptr, "topk_seed_bf16");
+            if (rc != HMX_OK) return rc;
+            hipLaunchKernelGGL(seed_threshold_kernel, dim3((unsigned)hmx_ceil_div(rows_pad, 256)), dim3(256), 0, s,
+                               out_scores + q0 * k, queries + q0 * d, nq, rows_pad, (int)d, (int)k, max_row_norm,
+                               init_thr);
+            HMX_CHECK_LAUNCH();
+            thr0 = init_thr;
         }
-        hmx_profile_end(span, s);
-        HMX_CHECK_LAUNCH();
-        RescoreParams r{};
-        r.q_f32 = queries + q0 * d;
-        r.t_f32 = table;
-        r.n_q = nq;
-        r.n_rows = n_rows;
-        r.d = (int)d;
-        r.NB = pl.NB;
-        r.KP = pl.KP;
-        r.cap = cap_for(pl.KP);
-        r.n_splits = pl.n_splits;
-        r.cand = cand;
-        r.meta_cnt = meta_cnt;
-        r.meta_thr = meta_thr;
-        r.k = (int)k;
-        r.id_offset = id_offset;
-        r.max_row_norm = bf16 ? max_row_norm : nullptr;
-        // bf16 pass: exclusions are applied here.  fp32 pass: the coarse kernel already skipped them.
-        r.exclude = (bf16 && excl) ? exclude + q0 * n_excl : nullptr;
-        r.n_excl = (int)n_excl;
-        r.out_ids = out_ids + q0 * k;
-        r.out_scores = out_scores + q0 * k;
-        r.uncertain = uncertain ? uncertain + q0 : nullptr;
-        launch_rescore(r, s);
-        HMX_CHECK_LAUNCH();
+        const int rc = pass(pl, n_rows, thr0, uncertain ? uncertain + q0 : nullptr,
+                            bf16 ? "topk_coarse_bf16" : "topk_coarse_f32");
+        if (rc != HMX_OK) return rc;
     }
     return HMX_OK;
 }
@@ -739,10 +836,10 @@ extern "C" int hmx_table_prepare_bf16(const float* table, int64_t n_rows, int64_
 }
 
 extern "C" size_t hmx_score_topk_workspace_bytes(int64_t n_q, int64_t n_rows, int64_t d, int64_t k) {
-    Plan a, b;
-    size_t need = 1024;
-    if (make_plan(n_q, n_rows, d, k, true, a)) need = std::max(need, a.total());
-    if (make_plan(n_q, n_rows, d, k, false, b)) need = std::max(need, b.total());
+    TopkPlans a, b;
+    size_t need = 1536;
+    if (make_plans(n_q, n_rows, d, k, true, a)) need = std::max(need, a.total());
+    if (make_plans(n_q, n_rows, d, k, false, b)) need = std::max(need, b.total());
     return need;
 }
 
