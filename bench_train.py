@@ -125,7 +125,9 @@ def run_train(args, world, rank, with_cpu_baseline=True):
         "metric": "user seqs/s hydra3 fwd+bwd", "value": B * world / step_s, "unit": "user seqs/s",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": step_s * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "hydra3 train step fwd+bwd with embedding scatter-add, batch 1024 x seq 100 (configs[1])",
+        "config": {"workload": f"hydra3 train step fwd+bwd with embedding scatter-add, batch {B} x seq {L}, d {d}" +
+                               (" (configs[1])" if (B, L, d) == (1024, 100, 64) else
+                                " (configs[4], per GPU)" if (L, d) == (512, 128) else ""),
                    "batch_per_gpu": B, "seq_len": L, "d": d, "users": args.users, "items": args.items,
                    "includes": "zero_grad, forward (encoder + miner top-50 + fused InfoNCE), backward, "
                                "clip_grad_norm, AdamW",

@@ -800,6 +800,76 @@ extern "C" int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X
     return HMX_OK;
 }
 
+// ---------------------------------------------------------------------------- plain linear recurrence
+// h[t] = a[t] * h[t-1] + x[t] over (B, L, C): one thread per (b, c) chain, consecutive c in consecutive lanes so
+// every step is one coalesced row access; four steps of loads are issued ahead of the dependent multiply-adds.
+__global__ __launch_bounds__(256) void pscan_fwd_kernel(const float* __restrict__ A, const float* __restrict__ X,
+                                                        int64_t B, int L, int64_t C, float* __restrict__ H) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * C) return;
+    const int64_t b = idx / C, c = idx % C;
+    const int64_t base = b * L * C + c;
+    float h = 0.f;
+    int t = 0;
+    for (; t + 4 <= L; t += 4) {
+        float a[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = A[base + (int64_t)(t + u) * C];
+            x[u] = X[base + (int64_t)(t + u) * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            h = a[u] * h + x[u];
+            H[base + (int64_t)(t + u) * C] = h;
+        }
+    }
+    for (; t < L; ++t) {
+        h = A[base + (int64_t)t * C] * h + X[base + (int64_t)t * C];
+        H[base + (int64_t)t * C] = h;
+    }
+}
+
+// g[t] = dH[t] + a[t+1] * g[t+1];  dX[t] = g[t];  dA[t] = g[t] * h[t-1]  (h[-1] = 0)
+__global__ __launch_bounds__(256) void pscan_bwd_kernel(const float* __restrict__ A, const float* __restrict__ H,
+                                                        const float* __restrict__ dH, int64_t B, int L, int64_t C,
+                                                        float* __restrict__ dA, float* __restrict__ dX) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * C) return;
+    const int64_t b = idx / C, c = idx % C;
+    const int64_t base = b * L * C + c;
+    float g = 0.f, a_next = 0.f;
+    for (int t = L - 1; t >= 0; --t) {
+        const int64_t o = base + (int64_t)t * C;
+        g = dH[o] + a_next * g;
+        const float h_prev = t > 0 ? H[o - C] : 0.f;
+        dX[o] = g;
+        dA[o] = g * h_prev;
+        a_next = A[o];
+    }
+}
+
+extern "C" int hmx_pscan_fwd(const float* A, const float* X, int64_t B, int64_t L, int64_t C, float* H, void* stream) {
+    HMX_ENTER();
+    if (B == 0 || L == 0 || C == 0) return HMX_OK;
+    if (!A || !X || !H || B < 0 || L < 0 || C < 0 || L >= ((int64_t)1 << 31)) return HMX_EINVAL;
+    hipLaunchKernelGGL(pscan_fwd_kernel, dim3((unsigned)hmx_ceil_div(B * C, 256)), dim3(256), 0, (hipStream_t)stream, A, X,
+                       B, (int)L, C, H);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_pscan_bwd(const float* A, const float* H, const float* dH, int64_t B, int64_t L, int64_t C,
+                             float* dA, float* dX, void* stream) {
+    HMX_ENTER();
+    if (B == 0 || L == 0 || C == 0) return HMX_OK;
+    if (!A || !H || !dH || !dA || !dX || B < 0 || L < 0 || C < 0 || L >= ((int64_t)1 << 31)) return HMX_EINVAL;
+    hipLaunchKernelGGL(pscan_bwd_kernel, dim3((unsigned)hmx_ceil_div(B * C, 256)), dim3(256), 0, (hipStream_t)stream, A, H,
+                       dH, B, (int)L, C, dA, dX);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
 extern "C" int hmx_silu_rope_fwd(const float* x1, const float* cos_t, const float* sin_t, int64_t T, int64_t L,
                                  int64_t d, int64_t hd, float* s, float* y2, void* stream) {
     HMX_ENTER();

@@ -372,6 +372,46 @@ def selective_scan_gated(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H):
     return _Scan.apply(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H)
 
 
+class _PScan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, X):
+        A, X = A.contiguous(), X.contiguous()
+        Bn, L = A.shape[0], A.shape[1]
+        C = A[0, 0].numel() if A.numel() else 0
+        H = torch.empty_like(X)
+        hmx.check(_L().hmx_pscan_fwd(hmx.ptr(A), hmx.ptr(X), Bn, L, C, hmx.ptr(H), _s()), "hmx_pscan_fwd")
+        ctx.save_for_backward(A, H)
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        A, H = ctx.saved_tensors
+        dH = dH.contiguous()
+        Bn, L = A.shape[0], A.shape[1]
+        C = A[0, 0].numel() if A.numel() else 0
+        dA, dX = torch.empty_like(A), torch.empty_like(A)
+        hmx.check(_L().hmx_pscan_bwd(hmx.ptr(A), hmx.ptr(H), hmx.ptr(dH), Bn, L, C, hmx.ptr(dA), hmx.ptr(dX), _s()),
+                  "hmx_pscan_bwd")
+        return dA, dX
+
+
+def pscan(A, X):
+    """hydra3.py:104: H[:, t] = A[:, t] * H[:, t-1] + X[:, t] for A, X of shape (B, L, ED, N)."""
+    if not (A.is_cuda and X.is_cuda) or A.dtype != torch.float32 or X.dtype != torch.float32 or A.shape != X.shape:
+        raise hmx.HmxError("pscan expects two CUDA float32 tensors of the same (B, L, ...) shape")
+    return _PScan.apply(A, X)
+
+
+def selective_scan(x, delta, A, B, C, D):
+    """hydra3.py:107-123 with the reference's own decomposition: deltaA = exp(delta (x) A), BX = delta * B * x,
+    hs = pscan(deltaA, BX) on HIP, y = <hs, C> + D * x.  (The model itself uses the fused scan kernel, which never
+    forms the (B, L, ED, N) tensors; this free function keeps the reference's call shape.)"""
+    dA = torch.exp(delta.unsqueeze(-1) * A)
+    bx = (delta.unsqueeze(-1) * B.unsqueeze(2)) * x.unsqueeze(-1)
+    hs = pscan(dA, bx)
+    return (hs * C.unsqueeze(2)).sum(-1) + D * x
+
+
 def seq_index(ids, ts, time_span):
     """(B, L) ids / timestamps -> padding mask (T,) float, position ids (T,), time bins (T,) (no gradient)."""
     _need_cuda(ids, ts)

@@ -12,6 +12,7 @@ from torch import nn
 
 from . import enc_ops as E
 from . import ops
+from .enc_ops import pscan, selective_scan   # noqa: F401  (hydra3.py:104, 107: same names, same call shapes)
 from .shared_embedding import SharedEmbeddingConfig, SharedEmbeddingModule
 
 D_STATE, DT_RANK, D_CONV = 16, 16, 4

@@ -207,6 +207,14 @@ int hmx_conv_silu_fwd(const float* x, const float* w, const float* b, int64_t T,
 int hmx_conv_silu_bwd(const float* x, const float* w, const float* b, const float* dxc, int64_t B, int64_t L,
                       int64_t C, float* dx, float* part, void* stream);
 
+/* pscan(A, X) (hydra3.py:16-104): H[b, t] = A[b, t] * H[b, t-1] + X[b, t], H[b, -1] = 0, for A, X, H of shape
+ * (B, L, C) with C = ED * N flattened.  The reference evaluates it with a Blelloch up/down sweep over L; this is
+ * the same recurrence evaluated sequentially in t (one chain per thread), so results agree to fp32 rounding.
+ * Backward: dX[t] = g[t], dA[t] = g[t] * H[t-1] with g[t] = dH[t] + A[t+1] * g[t+1]. */
+int hmx_pscan_fwd(const float* A, const float* X, int64_t B, int64_t L, int64_t C, float* H, void* stream);
+int hmx_pscan_bwd(const float* A, const float* H, const float* dH, int64_t B, int64_t L, int64_t C, float* dA,
+                  float* dX, void* stream);
+
 /* Selective scan of all heads (hydra3.py:107-123, 203-214) fused with the dt projection + softplus
  * (:210) and the SiLU(z) gate (:273).  C = H * ED channels, ED a power of two >= 32, state N = 16,
  * dt rank 16.  dbc (T, H, 48) = [dt_rank | B | C] rows of deltaBC_layer.  hs (T, C, 16), if not NULL,

@@ -263,3 +263,37 @@ def test_fast_bf16_mode_tolerance():
     close(out, G.t(s, p + "/out"), 3e-2, 1e-2, "log2feats fast mode")
     err = (out.cpu() - G.t(s, p + "/out")).abs().max().item()
     assert err > 1e-5          # it really was the rounded path
+
+
+# ---- free functions with the reference's call shapes (hydra3.py:104, 107-123) against the reference-captured goldens
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [1, 2, 3, 10, 25, 64, 100, 101, 512])
+def test_pscan_free_function_matches_reference_golden(L):
+    s, p = G.load("g1_pscan"), f"G1_pscan_L{L}"
+    A = G.t(s, p + "/A").cuda().requires_grad_()
+    X = G.t(s, p + "/X").cuda().requires_grad_()
+    Hh = E.pscan(A, X)
+    Hh.backward(G.t(s, p + "/G").cuda())
+    G.assert_close(Hh.cpu(), G.t(s, p + "/H"), 2e-5, 2e-5, "H")
+    G.assert_close(A.grad.cpu(), G.t(s, p + "/dA"), 1e-4, 1e-4, "dA")
+    G.assert_close(X.grad.cpu(), G.t(s, p + "/dX"), 1e-4, 1e-4, "dX")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_selective_scan_free_function_matches_reference_golden(case):
+    s, p = G.load("g2_selective_scan"), f"G2_sscan_{case}"
+    names = ["x", "delta", "A", "B", "C", "D"]
+    ins = [G.t(s, f"{p}/{n}").cuda().requires_grad_() for n in names]
+    y = E.selective_scan(*ins)
+    y.backward(G.t(s, p + "/G").cuda())
+    G.assert_close(y.cpu(), G.t(s, p + "/y"), 2e-5, 2e-5, "y")
+    for n, v in zip(names, ins):
+        G.assert_close(v.grad.cpu(), G.t(s, f"{p}/d{n}"), 1e-4, 1e-4, "d" + n)
+
+
+@pytest.mark.gpu
+def test_pscan_rejects_cpu_tensors():
+    from generative_recommenders_amd import hmx
+    with pytest.raises(hmx.HmxError):
+        E.pscan(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 4))
