@@ -4,9 +4,9 @@
 
 Workloads (synthetic data, shapes from BASELINE.json):
   retrieval  top-10 over a 4,000,001 x 64 item table for 1,000,000 user embeddings per step.
-             N > 1: the table is sharded by contiguous item-id range (one shard per GPU), every
-             rank scores all queries against its shard, per-shard lists are exchanged by RCCL
-             all_gather and merged (strong scaling: the work per step is fixed).
+             N > 1: the table is cut into S contiguous item-id ranges (--item-shards; default 2), the N / S
+             ranks holding a range split the queries, per-range lists are exchanged by RCCL all_gather and
+             merged (strong scaling: the work per step is fixed).  S = N is plain one-range-per-GPU sharding.
   train      hydra3 train step (forward + backward + clip + AdamW), batch 1024 x seq 100, d 64.
 A "step" is one pass of the hot path over one batch; inputs are resident in HBM before timing.
 """
@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--seq-len", type=int, default=100)
     ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--item-shards", type=int, default=0,
+                    help="item-id ranges the table is cut into (0: 2 when N is even, else N); N / shards ranks "
+                         "hold each range and split the queries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -101,10 +104,12 @@ def pmc_traffic(name):
 
 def run_retrieval(args, world, rank):
     from generative_recommenders_amd import hmx, synth
-    from generative_recommenders_amd.retrieval import ShardedRetriever, shard_bounds
+    from generative_recommenders_amd.retrieval import ShardedRetriever, grid_layout, shard_bounds
     dev = torch.device("cuda", torch.cuda.current_device())
     n_rows, d, k = args.items + 1, args.dim, 10
-    lo, hi = shard_bounds(n_rows, world, rank)
+    item_shards = args.item_shards if args.item_shards > 0 else (2 if world % 2 == 0 else world)
+    shard_index, S, qgroup, G = grid_layout(world, rank, item_shards)
+    lo, hi = shard_bounds(n_rows, S, shard_index)
     # every rank draws the same full table from one seed and keeps its rows: identical to the unsharded run
     full = synth.item_table(args.items, d, dev)
     shard = full[lo:hi].clone()
@@ -112,7 +117,7 @@ def run_retrieval(args, world, rank):
     del full
     torch.cuda.empty_cache()
     q = synth.queries(args.queries, d, dev)
-    retr = ShardedRetriever(shard, id_offset=lo)
+    retr = ShardedRetriever(shard, id_offset=lo, item_shards=S)
     for _ in range(args.warmup):
         retr.search(q, k)
     hmx.profile_enable(True)
@@ -130,7 +135,9 @@ def run_retrieval(args, world, rank):
     assert ids.shape == (args.queries, k) and bool((ids[:, 0] >= 0).all())
     step_s = elapsed / args.steps
     # dominant kernel: bf16 MFMA coarse scoring.  Algorithmic flops per launch = 2 * queries * rows * d.
-    flops_per_step = 2.0 * args.queries * (hi - lo) * d
+    per_group = -(-args.queries // G)
+    my_queries = max(0, min(per_group, args.queries - qgroup * per_group))
+    flops_per_step = 2.0 * my_queries * (hi - lo) * d
     achieved = flops_per_step * args.steps / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     traffic, traffic_src = pmc_traffic("r01_retrieval_pmc.json") if world == 1 else (None, None)
     out = {
@@ -140,7 +147,9 @@ def run_retrieval(args, world, rank):
         "data": "synthetic",
         "config": {"workload": "infer.py top-10 retrieval, 1M synthetic users x 4M items (configs[2]; sharded = configs[3])",
                    "queries": args.queries, "items": n_rows, "d": d, "k": k,
-                   "parallelism": f"item-range shards x{world}, all_gather merge" if world > 1 else "single GPU"},
+                   "parallelism": (f"{S} item-range shards x {G} query groups, RCCL all_gather + merge"
+                                   if world > 1 else "single GPU"),
+                   "item_shards": S, "query_groups": G},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per full 262144-query launch (FETCH_SIZE x 2 + WRITE_SIZE)",
