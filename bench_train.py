@@ -8,6 +8,8 @@ Differences from the reference's loop, stated here: compute is fp32 with bf16 MF
 kernels instead of fp16 autocast + GradScaler; the loss is one fused kernel over all masked positions
 (the reference's query chunking only bounds its memory; the fused loss kernel needs none).
 """
+import json
+import os
 import time
 
 import torch
@@ -119,6 +121,11 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     p_ms, p_n = hmx.profile_collect("gather_rows")
     hmx.profile_enable(False)
     probe_bytes = n_probe * (8 + 2 * d * 4)
+    traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gather_pmc.json")
+    if d == 64 and args.items == 4_000_000 and os.path.exists(pmc):    # counters were collected on this exact launch
+        with open(pmc) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     gather_gbs = probe_bytes * p_n / (p_ms * 1e-3) / 1e9 if p_ms > 0 else 0.0
     del pid
     out = {
@@ -134,7 +141,9 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                    "parallelism": f"dp{world}" if world > 1 else "single GPU"},
         "fwd_bwd_ms": fwd_bwd_ms, "fwd_bwd_seqs_per_s": B * world / (fwd_bwd_ms * 1e-3), "loss": float(loss.item()),
         "roofline": {"bound": "hbm", "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gather_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "gather_rows_kernel",
+                     "frac": gather_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r01_gather_pmc.json)",
+                     "kernel": "gather_rows_kernel",
                      "launch": f"{n_probe} uniform random ids over the {args.items + 1} x {d} item table",
                      "launches": p_n, "avg_launch_ms": p_ms / max(p_n, 1), "algorithmic_bytes_per_launch": probe_bytes},
         "other_kernels": {
