@@ -20,8 +20,14 @@ __device__ __forceinline__ void nt_store(const float4& v, float4* p) {
 }
 __device__ __forceinline__ void nt_store(const float& v, float* p) { __builtin_nontemporal_store(v, p); }
 
+// exact GELU, x * Phi(x) (F.gelu default, embedding.py:644)
+__device__ __forceinline__ float gelu1(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float4 vgelu(const float4& v) { return make_float4(gelu1(v.x), gelu1(v.y), gelu1(v.z), gelu1(v.w)); }
+__device__ __forceinline__ float vgelu(const float& v) { return gelu1(v); }
+
 // ROUTED: 0 = single table; 1 = item/user tables selected by token type (1 / 2, else zeros).
-template <int VEC, bool ROUTED>
+// GELU: the gathered row goes through GELU on its way out (candidate-embedding generation).
+template <int VEC, bool ROUTED, bool GELU>
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __restrict__ table0, int64_t rows0,
                                                              const float* __restrict__ table1, int64_t rows1,
                                                              int cpr, int lpr_log2,
@@ -60,13 +66,13 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
                 const int64_t r = base + (int64_t)u * rows_per_block;
                 // streaming store: the gathered copy is not read again by this kernel, so it should not evict
                 // table rows (which repeat) from L2 / Infinity Cache
-                if (r < n) nt_store(v[u], reinterpret_cast<V*>(out) + r * cpr + c);
+                if (r < n) nt_store(GELU ? vgelu(v[u]) : v[u], reinterpret_cast<V*>(out) + r * cpr + c);
             }
         }
     }
 }
 
-template <bool ROUTED>
+template <bool ROUTED, bool GELU = false>
 int launch_gather(const float* t0, int64_t r0, const float* t1, int64_t r1, int64_t d, const int64_t* ids,
                   const int64_t* tt, int64_t n, float* out, hipStream_t s) {
     if (n == 0) return HMX_OK;
@@ -78,10 +84,10 @@ int launch_gather(const float* t0, int64_t r0, const float* t1, int64_t r1, int6
     const int grid = (int)std::min<int64_t>(hmx_ceil_div(n, rows_per_block), kMaxGrid);
     void* span = hmx_profile_begin("gather_rows", s);
     if (vec)
-        hipLaunchKernelGGL((gather_rows_kernel<4, ROUTED>), dim3(grid), dim3(kBlock), 0, s, t0, r0, t1, r1, (int)cpr,
+        hipLaunchKernelGGL((gather_rows_kernel<4, ROUTED, GELU>), dim3(grid), dim3(kBlock), 0, s, t0, r0, t1, r1, (int)cpr,
                            l2, ids, tt, n, out);
     else
-        hipLaunchKernelGGL((gather_rows_kernel<1, ROUTED>), dim3(grid), dim3(kBlock), 0, s, t0, r0, t1, r1, (int)cpr,
+        hipLaunchKernelGGL((gather_rows_kernel<1, ROUTED, GELU>), dim3(grid), dim3(kBlock), 0, s, t0, r0, t1, r1, (int)cpr,
                            l2, ids, tt, n, out);
     hmx_profile_end(span, s);
     HMX_CHECK_LAUNCH();
@@ -96,6 +102,14 @@ extern "C" int hmx_gather_rows_f32(const float* table, int64_t n_rows, int64_t d
     if (n < 0 || d <= 0 || n_rows <= 0) return HMX_EINVAL;
     if (n > 0 && (!table || !ids || !out)) return HMX_EINVAL;
     return launch_gather<false>(table, n_rows, nullptr, 0, d, ids, nullptr, n, out, (hipStream_t)stream);
+}
+
+extern "C" int hmx_gather_gelu_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n,
+                                        float* out, void* stream) {
+    HMX_ENTER();
+    if (n < 0 || d <= 0 || n_rows <= 0) return HMX_EINVAL;
+    if (n > 0 && (!table || !ids || !out)) return HMX_EINVAL;
+    return launch_gather<false, true>(table, n_rows, nullptr, 0, d, ids, nullptr, n, out, (hipStream_t)stream);
 }
 
 extern "C" int hmx_gather_routed_f32(const float* item_table, int64_t item_rows, const float* user_table,

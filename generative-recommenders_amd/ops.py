@@ -87,6 +87,19 @@ def gather_rows(weight, ids, padding_idx=None):
     return _GatherRows.apply(weight, ids, padding_idx)
 
 
+@torch.no_grad()
+def gather_gelu_rows(weight, ids):
+    """out[..., :] = GELU(weight[ids[...], :]) in one pass (candidate-embedding generation; no gradient)."""
+    _need_cuda(weight, ids)
+    w = _f32c(weight.detach())
+    idc = _i64c(ids)
+    _validate_ids(idc, w.shape[0], "gather_gelu_rows")
+    out = torch.empty(*idc.shape, w.shape[1], dtype=torch.float32, device=w.device)
+    hmx.check(hmx.lib().hmx_gather_gelu_rows_f32(hmx.ptr(w), w.shape[0], w.shape[1], hmx.ptr(idc), idc.numel(),
+                                                 hmx.ptr(out), hmx.current_stream()), "hmx_gather_gelu_rows_f32")
+    return out
+
+
 class _GatherRouted(torch.autograd.Function):
     @staticmethod
     def forward(ctx, item_w, user_w, ids, token_type):

@@ -73,3 +73,30 @@ class SharedEmbeddingModule(nn.Module):
         if fusion_style == 'late':
             return torch.nn.functional.gelu(base)
         return torch.cat([base, torch.zeros_like(base)], dim=2)
+
+    @torch.no_grad()
+    def _late_item_rows(self, ids):
+        """GELU(item_emb[ids]) fused into the row gather: what get_complete_embeddings(ids[:, None], ...,
+        include_user=False, fusion_style='late').squeeze(1) returns in the ids-only configuration."""
+        return ops.gather_gelu_rows(self.item_emb.weight, ids)
+
+    @torch.no_grad()
+    def get_item_embeddings(self, feat_dict=None, batch_size=1024):
+        """embedding.py:686-735: (item_num + 1, d) candidate table, row 0 zeros, row i = late-fusion embedding of
+        item i.  `batch_size` only bounded the reference's memory; one fused pass covers every row here."""
+        ids = torch.arange(1, self.item_num + 1, device=self.item_emb.weight.device)
+        out = torch.empty(self.item_num + 1, self.item_emb.embedding_dim, device=ids.device)
+        out[0].zero_()
+        out[1:] = self._late_item_rows(ids)
+        return out
+
+    @torch.no_grad()
+    def save_item_embeddings(self, item_ids, retrieval_ids, feat_dict, save_path, batch_size=1024):
+        """embedding.py:654-684: embedding.fbin (late-fusion rows of `item_ids`) and id.u64bin (`retrieval_ids`)."""
+        import numpy as np
+        from pathlib import Path
+        from .ann_files import save_emb
+        ids = torch.as_tensor(list(item_ids), dtype=torch.int64, device=self.item_emb.weight.device)
+        embs = self._late_item_rows(ids).cpu().numpy().astype(np.float32)
+        save_emb(embs, Path(save_path, 'embedding.fbin'))
+        save_emb(np.array(list(retrieval_ids), dtype=np.uint64).reshape(-1, 1), Path(save_path, 'id.u64bin'))

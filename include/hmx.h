@@ -50,6 +50,13 @@ int hmx_gather_routed_f32(const float* item_table, int64_t item_rows, const floa
                           int64_t d, const int64_t* ids, const int64_t* token_type, int64_t n, float* out,
                           void* stream);
 
+/* out[i, :] = GELU(table[ids[i], :]) (exact erf form), the candidate-embedding generation of
+ * embedding.py:654-735 in the ids-only configuration: get_complete_embeddings(..., fusion_style='late') is
+ * F.gelu(item_emb[ids] + 0) (embedding.py:641-644).  Same id handling as hmx_gather_rows_f32 (an id out of
+ * range reads as a zero row, GELU(0) = 0).  Inference only (no backward). */
+int hmx_gather_gelu_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n, float* out,
+                             void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Scatter-add of gradient rows (backward of the gathers above).
  *   grad_table[ids[i], :] += grad_rows[i, :]   for every i with ids[i] != padding_idx,

@@ -282,6 +282,17 @@ class SharedEmbeddingModule(nn.Module):
         return torch.cat([base, feat], dim=2)
 
 
+def late_item_rows(item_weight, ids):
+    """embedding.py:641-644 with the ids-only zero feature block: F.gelu(item_emb[ids] + 0)."""
+    return F.gelu(item_weight[ids])
+
+
+def item_embedding_table(item_weight):
+    """embedding.py:686-735: row 0 zeros, row i = late-fusion embedding of item i."""
+    n = item_weight.shape[0]
+    return torch.cat([torch.zeros(1, item_weight.shape[1]), late_item_rows(item_weight, torch.arange(1, n))], dim=0)
+
+
 def time_bins_from_timestamps(log_seqs, seq_timestamp, time_span=512):
     """hydra3.py:650-659: bin = min(floor(ln(dt + 1)), time_span-1) * (id != 0)."""
     dt = torch.zeros_like(seq_timestamp)

@@ -287,15 +287,42 @@ def g10_train(store):
                 store[f"{prefix}/grad/{k}"] = g.numpy()
 
 
+def g11_item_embs(store):
+    """Candidate-table generation (embedding.py:654-735) in the ids-only configuration."""
+    m, a = build_ref_model(20, 60, 16, 10, 0.0, seed=21)
+    se = m.shared_embeddings
+    m.eval()
+    with torch.no_grad(), quiet(), contextlib.redirect_stderr(io.StringIO()):
+        full = se.get_item_embeddings({}, batch_size=16)
+        saved = []
+        _stub.save_emb = lambda arr, path: saved.append((os.path.basename(str(path)), np.array(arr)))
+        ref_emb.save_emb = _stub.save_emb
+        item_ids = [5, 1, 60, 33, 2, 17, 9]
+        retrieval_ids = [105, 101, 160, 133, 102, 117, 109]
+        se.save_item_embeddings(item_ids, retrieval_ids, {i: {} for i in range(len(item_ids))}, "/nonexistent", batch_size=3)
+        seq = torch.tensor([[3, 0, 7], [60, 1, 1]])
+        late = se.get_complete_embeddings(seq, [[{}] * 3] * 2, include_user=False, fusion_style="late")
+        early = se.get_complete_embeddings(seq, [[{}] * 3] * 2, include_user=False, fusion_style="early")
+    put(store, "G11", item_w=se.item_emb.weight, full=full, seq=seq, late=late, early=early,
+        item_ids=torch.tensor(item_ids), retrieval_ids=torch.tensor(retrieval_ids))
+    for name, arr in saved:
+        store["G11/saved/" + name] = arr
+
+
 def main():
+    only = set(sys.argv[1:])
     groups = {"g1_pscan": g1_pscan, "g2_selective_scan": g2_selective_scan, "g3_rmsnorm": g3_rmsnorm,
               "g4_mamba": g4_mamba, "g5_mhm": g5_mhm, "g6_blocks": g6_blocks, "g7_multiscale": g7_multiscale,
-              "g9_topk": g9_topk, "g10_train": g10_train}
+              "g9_topk": g9_topk, "g10_train": g10_train, "g11_item_embs": g11_item_embs}
     for fname, fn in groups.items():
+        if only and fname not in only:
+            continue
         store = {}
         fn(store)
         np.savez_compressed(os.path.join(OUT, fname + ".npz"), **store)
         print(fname, len(store), "arrays")
+    if only and "g8_log2feats" not in only:
+        return
     store, keys = {}, {}
     g8_log2feats(store, keys)
     np.savez_compressed(os.path.join(OUT, "g8_log2feats.npz"), **store)

@@ -97,3 +97,27 @@ def test_retrieve_files_on_gpu_matches_oracle(tmp_path):
     got = A.read_result_ids(tmp_path / "id100.u64bin")
     want_rows, _ = C.score_topk(queries, table, 10)
     assert np.array_equal(got, ids[want_rows])
+
+
+@pytest.mark.gpu
+def test_candidate_table_generation_matches_reference_golden(tmp_path):
+    """SharedEmbeddingModule.get_item_embeddings / save_item_embeddings / get_complete_embeddings on the fused
+    gather+GELU kernel against outputs captured from the reference (embedding.py:613-735, ids-only)."""
+    import _golden as G
+    from generative_recommenders_amd import hydra as H
+    s = G.load("g11_item_embs")
+    args = H.make_args(d=16, L=10, device="cuda")
+    m = H.Hydra(20, 60, {}, H.IDS_ONLY_FEAT_TYPES, args).cuda()
+    se = m.shared_embeddings
+    with torch.no_grad():
+        se.item_emb.weight.copy_(G.t(s, "G11/item_w"))
+    full = se.get_item_embeddings({})
+    assert full.shape == (61, 16) and bool((full[0] == 0).all())
+    G.assert_close(full.cpu(), G.t(s, "G11/full"), 2e-6, 2e-7, "full")
+    seq = G.t(s, "G11/seq").cuda()
+    G.assert_close(se.get_complete_embeddings(seq, None, fusion_style="late").cpu(), G.t(s, "G11/late"), 2e-6, 2e-7, "late")
+    G.assert_close(se.get_complete_embeddings(seq, None, fusion_style="early").cpu(), G.t(s, "G11/early"), 0, 0, "early")
+    se.save_item_embeddings(G.t(s, "G11/item_ids").tolist(), G.t(s, "G11/retrieval_ids").tolist(), {}, tmp_path)
+    G.assert_close(torch.from_numpy(A.load_fbin(tmp_path / "embedding.fbin")), G.t(s, "G11/saved/embedding.fbin"),
+                   2e-6, 2e-7, "embedding.fbin")
+    assert np.array_equal(A.load_u64bin(tmp_path / "id.u64bin"), s["G11/saved/id.u64bin"].reshape(-1))

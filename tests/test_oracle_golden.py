@@ -158,3 +158,12 @@ def test_train_step_loss_and_grads(name):
         assert torch.equal(g.abs().sum(1).nonzero().flatten(), rows), k
         G.assert_close(g[rows], vals, 1e-3, 2e-5, "table grad " + k)
         assert float(g[0].abs().sum()) == 0.0
+
+
+def test_candidate_embedding_generation_matches_reference():
+    """embedding.py:654-735 (ids-only): the oracle's late-fusion rows against what the reference produced."""
+    s = G.load("g11_item_embs")
+    w = G.t(s, "G11/item_w")
+    G.assert_close(O.item_embedding_table(w), G.t(s, "G11/full"), 1e-6, 1e-7, "full table")
+    G.assert_close(O.late_item_rows(w, G.t(s, "G11/seq")), G.t(s, "G11/late"), 1e-6, 1e-7, "late")
+    G.assert_close(O.late_item_rows(w, G.t(s, "G11/item_ids")), G.t(s, "G11/saved/embedding.fbin"), 1e-6, 1e-7, "saved")
