@@ -849,6 +849,120 @@ __global__ __launch_bounds__(256) void pscan_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------- one-query attention
+// The fusion tail of the multi-scale encoder (hydra3.py:528-533): per sequence ONE query attends over the L
+// positions of the long-term representation.  kv rows are [k (d) | v (d)] per token, heads are column blocks of
+// hd = d / H.  One wave per (sequence, head): lanes own positions for the scores and the softmax, then own
+// feature columns for the weighted sums (weights parked in LDS).  No key-padding mask (the reference passes none).
+// drop (B, H, L), optional: multiplier of the attention weights (0 or 1 / (1 - p)), i.e. the module's dropout.
+constexpr int kAttnMaxL = 4096;
+
+__global__ __launch_bounds__(64) void attn1q_fwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                        const float* __restrict__ drop, int L, int d, int H,
+                                                        float* __restrict__ p_out, float* __restrict__ out) {
+    __shared__ float w_sh[kAttnMaxL];
+    const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    const int hd = d / H;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float* qh = q + (int64_t)b * d + h * hd;
+    const float* kvb = kv + (int64_t)b * L * 2 * d;
+    float mx = -INFINITY;
+    for (int l = lane; l < L; l += 64) {
+        const float* kr = kvb + (int64_t)l * 2 * d + h * hd;
+        float s = 0.f;
+        for (int j = 0; j < hd; ++j) s = __builtin_fmaf(qh[j], kr[j], s);
+        s *= scale;
+        w_sh[l] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+    for (int l = lane; l < L; l += 64) {
+        const float e = expf(w_sh[l] - mx);
+        w_sh[l] = e;
+        sum += e;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.0f / sum;
+    for (int l = lane; l < L; l += 64) {
+        const float pr = w_sh[l] * inv;
+        p_out[((int64_t)b * H + h) * L + l] = pr;
+        w_sh[l] = drop ? pr * drop[((int64_t)b * H + h) * L + l] : pr;
+    }
+    __syncthreads();
+    for (int j = lane; j < hd; j += 64) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc = __builtin_fmaf(w_sh[l], kvb[(int64_t)l * 2 * d + d + h * hd + j], acc);
+        out[(int64_t)b * d + h * hd + j] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void attn1q_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                        const float* __restrict__ drop, const float* __restrict__ p_in,
+                                                        const float* __restrict__ dout, int L, int d, int H,
+                                                        float* __restrict__ dq, float* __restrict__ dkv) {
+    __shared__ float ds_sh[kAttnMaxL];   // d score
+    __shared__ float wv_sh[kAttnMaxL];   // weight that multiplied v (p * drop)
+    const int b = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    const int hd = d / H;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float* qh = q + (int64_t)b * d + h * hd;
+    const float* doh = dout + (int64_t)b * d + h * hd;
+    const float* kvb = kv + (int64_t)b * L * 2 * d;
+    float* dkvb = dkv + (int64_t)b * L * 2 * d;
+    const float* pb = p_in + ((int64_t)b * H + h) * L;
+    const float* db = drop ? drop + ((int64_t)b * H + h) * L : nullptr;
+    // dw[l] = drop[l] * <dout, v_l>;  dot = sum_l p[l] dw[l];  ds[l] = p[l] (dw[l] - dot)
+    float dot = 0.f;
+    for (int l = lane; l < L; l += 64) {
+        const float* vr = kvb + (int64_t)l * 2 * d + d + h * hd;
+        float dw = 0.f;
+        for (int j = 0; j < hd; ++j) dw = __builtin_fmaf(doh[j], vr[j], dw);
+        const float m = db ? db[l] : 1.0f;
+        dw *= m;
+        ds_sh[l] = dw;
+        wv_sh[l] = pb[l] * m;
+        dot += pb[l] * dw;
+    }
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    for (int l = lane; l < L; l += 64) ds_sh[l] = pb[l] * (ds_sh[l] - dot) * scale;   // includes the 1/sqrt(hd)
+    __syncthreads();
+    for (int j = lane; j < hd; j += 64) {
+        float acc = 0.f;
+        const float qj = qh[j], dj = doh[j];
+        for (int l = 0; l < L; ++l) {
+            const int64_t o = (int64_t)l * 2 * d + h * hd + j;
+            acc = __builtin_fmaf(ds_sh[l], kvb[o], acc);
+            dkvb[o] = ds_sh[l] * qj;          // d k
+            dkvb[o + d] = wv_sh[l] * dj;      // d v
+        }
+        dq[(int64_t)b * d + h * hd + j] = acc;
+    }
+}
+
+extern "C" int hmx_attn1q_fwd(const float* q, const float* kv, const float* drop, int64_t B, int64_t L, int64_t d,
+                              int64_t H, float* p_out, float* out, void* stream) {
+    HMX_ENTER();
+    if (B == 0) return HMX_OK;
+    if (!q || !kv || !p_out || !out || L <= 0 || L > kAttnMaxL || d <= 0 || H <= 0 || d % H) return HMX_EINVAL;
+    hipLaunchKernelGGL(attn1q_fwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, q, kv, drop, (int)L,
+                       (int)d, (int)H, p_out, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_attn1q_bwd(const float* q, const float* kv, const float* drop, const float* p, const float* dout,
+                              int64_t B, int64_t L, int64_t d, int64_t H, float* dq, float* dkv, void* stream) {
+    HMX_ENTER();
+    if (B == 0) return HMX_OK;
+    if (!q || !kv || !p || !dout || !dq || !dkv || L <= 0 || L > kAttnMaxL || d <= 0 || H <= 0 || d % H)
+        return HMX_EINVAL;
+    hipLaunchKernelGGL(attn1q_bwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, q, kv, drop, p, dout,
+                       (int)L, (int)d, (int)H, dq, dkv);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
 extern "C" int hmx_pscan_fwd(const float* A, const float* X, int64_t B, int64_t L, int64_t C, float* H, void* stream) {
     HMX_ENTER();
     if (B == 0 || L == 0 || C == 0) return HMX_OK;

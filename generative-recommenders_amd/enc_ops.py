@@ -372,6 +372,37 @@ def selective_scan_gated(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H):
     return _Scan.apply(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H)
 
 
+class _Attn1Q(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, drop, L, H):
+        _need_cuda(q, kv)
+        q, kv = _f32c(q), _f32c(kv)
+        B, d = q.shape
+        assert kv.shape == (B * L, 2 * d)
+        drop = _f32c(drop) if drop is not None else None
+        p = _empty(B, H, L, like=q)
+        out = _empty(B, d, like=q)
+        hmx.check(_L().hmx_attn1q_fwd(hmx.ptr(q), hmx.ptr(kv), hmx.ptr(drop), B, L, d, H, hmx.ptr(p), hmx.ptr(out), _s()),
+                  "hmx_attn1q_fwd")
+        ctx.save_for_backward(q, kv, drop, p)
+        ctx.dims = (B, L, d, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, drop, p = ctx.saved_tensors
+        B, L, d, H = ctx.dims
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        hmx.check(_L().hmx_attn1q_bwd(hmx.ptr(q), hmx.ptr(kv), hmx.ptr(drop), hmx.ptr(p), hmx.ptr(_f32c(dout)), B, L, d, H,
+                                      hmx.ptr(dq), hmx.ptr(dkv), _s()), "hmx_attn1q_bwd")
+        return dq, dkv, None, None, None
+
+
+def attn1q(q, kv, drop, L, H):
+    """One query per sequence over L projected [k | v] rows (hydra3.py:528-533); drop: (B, H, L) multiplier or None."""
+    return _Attn1Q.apply(q, kv, drop, L, H)
+
+
 class _PScan(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, X):

@@ -158,8 +158,9 @@ class HydraBlock(_HydraBlockBase):
 
 
 class MultiScaleUserEncoder(nn.Module):
-    """hydra3.py:460-548.  The three HydraBlocks run on the HIP kernels; the one-query fusion tail (B x 1 tokens)
-    is composed of PyTorch ops."""
+    """hydra3.py:460-548.  The three HydraBlocks, the attention's projections, the one-query attention, the gate's
+    Linear, the RMSNorm and the output projection run on the HIP kernels; the (B, d) elementwise glue of the
+    tail (sigmoid, the convex mix, the final broadcast add) is PyTorch."""
 
     def __init__(self, dim, dt_rank, dim_inner, d_state, args):
         super().__init__()
@@ -181,11 +182,27 @@ class MultiScaleUserEncoder(nn.Module):
         short = self.short_term_encoder(sequence[:, -sw:].contiguous(), sm)
         mid = self.mid_term_encoder(sequence[:, -mw:].contiguous(), mm)
         long_ = self.long_term_encoder(sequence, padding_mask)
-        sf, mf, lf = short[:, -1:], mid[:, -1:], long_[:, -1:]
-        att, _ = self.cross_attention(query=sf, key=long_, value=long_, need_weights=False)
-        g = self.fusion_gate(torch.cat([sf, mf, lf], dim=-1))
-        fused = self.output_proj(self.norm(g * att + (1 - g) * lf))
-        return long_ + 0.5 * fused
+        B, _, d = long_.shape
+        sf, mf, lf = short[:, -1].contiguous(), mid[:, -1].contiguous(), long_[:, -1].contiguous()
+        # nn.MultiheadAttention(query=sf, key=value=long_) spelled out on the HIP kernels: in-projections,
+        # one-query attention (dropout on the weights as the module applies it in training), out-projection
+        ca = self.cross_attention
+        H = ca.num_heads
+        W, bias = ca.in_proj_weight, ca.in_proj_bias
+        q = E.linear(sf, W[:d], bias[:d])
+        kv = E.linear(long_.reshape(B * L, d), W[d:], bias[d:])
+        drop = None
+        if self.training and ca.dropout > 0.0:
+            keep = 1.0 - ca.dropout
+            drop = (torch.rand(B, H, L, device=long_.device) < keep).float() / keep
+        att = E.linear(E.attn1q(q, kv, drop, L, H), ca.out_proj.weight, ca.out_proj.bias)
+        gate = self.fusion_gate[0]        # Linear(3d -> d) on cat[sf, mf, lf], as three column blocks
+        g = E.linear(sf, gate.weight[:, :d], gate.bias)
+        g = E.linear(mf, gate.weight[:, d:2 * d], None, r1=g, c1=1.0)
+        g = torch.sigmoid(E.linear(lf, gate.weight[:, 2 * d:], None, r1=g, c1=1.0))
+        mixed = g * att + (1 - g) * lf
+        fused = E.linear(E.rmsnorm(mixed, self.norm.scale, self.norm.eps), self.output_proj.weight, self.output_proj.bias)
+        return long_ + 0.5 * fused.view(B, 1, d)
 
 
 class PositionAwareEncoder(nn.Module):

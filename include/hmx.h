@@ -214,6 +214,17 @@ int hmx_conv_silu_fwd(const float* x, const float* w, const float* b, int64_t T,
 int hmx_conv_silu_bwd(const float* x, const float* w, const float* b, const float* dxc, int64_t B, int64_t L,
                       int64_t C, float* dx, float* part, void* stream);
 
+/* One-query multi-head attention of the multi-scale fusion tail (hydra3.py:528-533: nn.MultiheadAttention with
+ * query = the short-term encoder's last token, key = value = the long-term representation; no key-padding mask).
+ * q (B, d) and kv (B * L, 2d) = [k | v] are the ALREADY PROJECTED inputs (in_proj through hmx_linear_f32), heads are
+ * column blocks of d / H.  out[b, h-block] = sum_l softmax_l(<q, k_l> / sqrt(d/H)) * drop[b, h, l] * v_l.
+ * drop (B, H, L) is the dropout multiplier of the attention weights (NULL in eval).  p (B, H, L) receives the
+ * softmax weights for the backward pass, which writes dq (B, d) and dkv (B * L, 2d).  L <= 4096. */
+int hmx_attn1q_fwd(const float* q, const float* kv, const float* drop, int64_t B, int64_t L, int64_t d, int64_t H,
+                   float* p, float* out, void* stream);
+int hmx_attn1q_bwd(const float* q, const float* kv, const float* drop, const float* p, const float* dout, int64_t B,
+                   int64_t L, int64_t d, int64_t H, float* dq, float* dkv, void* stream);
+
 /* pscan(A, X) (hydra3.py:16-104): H[b, t] = A[b, t] * H[b, t-1] + X[b, t], H[b, -1] = 0, for A, X, H of shape
  * (B, L, C) with C = ED * N flattened.  The reference evaluates it with a Blelloch up/down sweep over L; this is
  * the same recurrence evaluated sequentially in t (one chain per thread), so results agree to fp32 rounding.
