@@ -20,6 +20,7 @@
 //   thresholds are exact and every query is certain.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "hmx_common.h"
 #include "profile.h"
@@ -50,6 +51,7 @@ struct CoarseParams {
     int n_excl;
     int64_t id_offset;
     const float* init_thr;    // (n_q_pad) starting threshold per query or null (-inf)   [bf16 pass]
+    int* ring_error;          // set to 1 if a wave of the ring kernel gave up waiting (results then flagged uncertain)
     uint2* cand;              // [wave][g][lane][CAP] (score bits, local row)
     int* meta_cnt;            // [wave][g][lane]
     float* meta_thr;          // [wave][g][lane]
@@ -125,6 +127,8 @@ __device__ __forceinline__ void tile_filter(const f32x16& acc, float& thr, int& 
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
     if (__ballot(m > thr) == 0ull) return;  // wave-uniform fast path
+    // keep the sixteen row numbers out of the fast path: without this the compiler computes them before the branch
+    asm volatile("" : "+v"(row0));
     uint2* mine = group_buf + (threadIdx.x & 63) * CAP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -278,6 +282,263 @@ __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
                          p.meta_thr + (wave * NB + g) * 64);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 coarse pass, shared-stream form (d = 64): the eight waves of a workgroup (eight query tiles) consume ONE
+// stream of item rows through a ring of kStages LDS stages of kStageTiles tiles each, so the rows cross L2 -> CU
+// once per eight query tiles instead of once per tile.  No barrier in the loop: stage s is fetched by wave
+// s % 8 with global -> LDS DMA while that wave is kLookahead stages earlier in its own consumption; a stage is
+// published through an LDS generation counter and retired through an LDS completion counter, so the waves may
+// drift up to kStages - kLookahead stages apart (the filter's slow path makes their speeds uneven).
+// Progress: the wave that is furthest behind never waits -- every stage it needs was published by a wave that is
+// ahead of it, and the slot it must overwrite was retired by everyone -- so the ring cannot deadlock.  The waits
+// are bounded all the same; a wave that gives up sets ring_error and the launch's queries are re-run exactly.
+// LDS rows are 128 B; the 16-byte chunk c of row r sits at chunk position c ^ (r & 7), which spreads the eight
+// rows read by neighbouring lanes over all banks without padding (the DMA needs a dense destination).
+constexpr int kRingWaves = 8;
+constexpr int kStageTiles = 4;
+constexpr int kStages = 8;
+constexpr int kLookahead = 5;
+constexpr int kStageBytes = kStageTiles * 32 * 128;
+constexpr int kRingSpinLimit = 1 << 22;
+
+template <int NB, int KP>
+__global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(CoarseParams p) {
+    constexpr int KS = 4;
+    constexpr int CAP = cap_for(KP);
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    __shared__ int ready[kStages];   // generation (stage / kStages + 1) of the data in each slot
+    __shared__ int done[kStages];    // waves that finished with the slot, summed over generations
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int n_wg_tiles = p.n_qtiles / kRingWaves;
+    const int wg_tile = blockIdx.x % n_wg_tiles, split = blockIdx.x / n_wg_tiles;
+    const int qtile = wg_tile * kRingWaves + w;
+    const int64_t wave = (int64_t)qtile * p.n_splits + split;
+    const int64_t row_begin = (int64_t)split * p.rows_per_split;
+    const int64_t row_end = min(row_begin + p.rows_per_split, p.n_rows);
+    uint2* wave_buf = p.cand + wave * NB * 64 * CAP;
+    if (tid < kStages) {
+        ready[tid] = 0;
+        done[tid] = 0;
+    }
+
+    short8 bq[NB][KS];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const int64_t qrow = (int64_t)qtile * 32 * NB + 32 * g + j;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            bq[g][ks] = *reinterpret_cast<const short8*>(p.q_bf16 + qrow * p.dpad + 16 * ks + 8 * h);
+    }
+    float thr[NB];
+    int cnt[NB];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        thr[g] = p.init_thr ? p.init_thr[(int64_t)qtile * 32 * NB + 32 * g + j] : kNegInf;
+        cnt[g] = 0;
+    }
+    const int n_rows_here = (int)max(row_end - row_begin, (int64_t)0);
+    const int n_tiles = (n_rows_here + 31) / 32;
+    const int n_stages = (n_tiles + kStageTiles - 1) / kStageTiles;
+
+    // This wave fetches a whole stage: 16 DMA instructions of 64 lanes x 16 B; instruction i covers rows 8i..8i+7
+    // of the stage and lands dense in LDS (lane order).  Lane l serves row 8i + (l >> 3) and writes chunk position
+    // l & 7, so it reads logical chunk (l & 7) ^ (l >> 3): per lane the source is one pointer plus i * 1024 B.
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+    auto fetch_stage = [&](int s, bool clamp) {
+        char* dst = smem + (s % kStages) * kStageBytes;
+        const int64_t base_row = row_begin + (int64_t)s * (kStageTiles * 32) + lrow;
+        const uint16_t* src0 = p.t_bf16 + base_row * 64 + 8 * lchunk;
+#pragma unroll
+        for (int i = 0; i < kStageBytes / 1024; ++i) {
+            const uint16_t* src = src0 + i * 512;
+            if (clamp) src = p.t_bf16 + min(base_row + 8 * i, row_end - 1) * 64 + 8 * lchunk;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+    auto publish = [&](int s) {   // after the stage's DMA has landed
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): every DMA of this wave has written LDS
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&ready[s % kStages], s / kStages + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_at_least = [&](int* flag, int target) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kRingSpinLimit) {
+                if (lane == 0) *p.ring_error = 1;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    const int n_full_stages = n_rows_here / (kStageTiles * 32);   // stages whose 128 rows all exist
+    int pending = -1;
+    // what a wave does on entering stage c: its fetching duty for stage c + kLookahead, then wait for stage c
+    auto enter_stage = [&](int c) {
+        const int ahead = c + kLookahead;
+        if (ahead < n_stages && (ahead % kRingWaves) == w) {
+            wait_at_least(&done[ahead % kStages], kRingWaves * (ahead / kStages));   // slot retired by all eight
+            fetch_stage(ahead, ahead >= n_full_stages);
+            pending = ahead;
+        }
+        wait_at_least(&ready[c % kStages], c / kStages + 1);
+    };
+    auto leave_stage = [&](int c) {
+        if (pending >= 0) {
+            publish(pending);
+            pending = -1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's LDS reads of the slot are complete
+        if (lane == 0) __hip_atomic_fetch_add(&done[c % kStages], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // A fragments of tile tl of a stage image: row tl * 32 + j, logical chunk 2 ks + h, swizzled by (row & 7) = (j & 7)
+    int a_off[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a_off[ks] = j * 128 + 16 * ((2 * ks + h) ^ (j & 7));
+    auto read_tile = [&](short8(&a)[KS], const char* img, int tl) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const short8*>(img + tl * 4096 + a_off[ks]);
+    };
+    auto compute_tile = [&](const short8(&a)[KS], int t, bool may_be_partial) {
+        f32x16 acc[NB];
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[g][q] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bq[g][ks], acc[g], 0, 0, 0);
+        }
+        const int row0 = (int)row_begin + 32 * t + 4 * h;
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            if (may_be_partial && (t + 1) * 32 > n_rows_here) mask_tail_rows(acc[g], row0, (int)row_end);
+            tile_filter<KP, false>(acc[g], thr[g], cnt[g], wave_buf + g * 64 * CAP, row0, p, 0);
+        }
+    };
+
+    __syncthreads();                      // counters cleared
+    if (w < kLookahead && w < n_stages) {
+        fetch_stage(w, w >= n_full_stages);
+        publish(w);
+    }
+    // Full stages, four tiles each, software-pipelined: the LDS reads of the next tile are issued before the
+    // MFMAs of the current one (two fragment buffers), also across the stage boundary.
+    short8 a0[KS], a1[KS];
+    if (n_full_stages > 0) {
+        enter_stage(0);
+        read_tile(a0, smem, 0);
+    }
+    for (int c = 0; c < n_full_stages; ++c) {
+        const char* img = smem + (c % kStages) * kStageBytes;
+        const int t = c * kStageTiles;
+        read_tile(a1, img, 1);
+        compute_tile(a0, t, false);
+        read_tile(a0, img, 2);
+        compute_tile(a1, t + 1, false);
+        read_tile(a1, img, 3);
+        compute_tile(a0, t + 2, false);
+        if (c + 1 < n_full_stages) {
+            enter_stage(c + 1);
+            read_tile(a0, smem + ((c + 1) % kStages) * kStageBytes, 0);
+        }
+        compute_tile(a1, t + 3, false);
+        leave_stage(c);
+    }
+    if (n_full_stages < n_stages) {       // the last, short stage: plain read-then-compute
+        const int c = n_full_stages;
+        enter_stage(c);
+        const char* img = smem + (c % kStages) * kStageBytes;
+        const int tiles_here = n_tiles - c * kStageTiles;
+        for (int tl = 0; tl < tiles_here; ++tl) {
+            read_tile(a0, img, tl);
+            compute_tile(a0, c * kStageTiles + tl, true);
+        }
+        leave_stage(c);
+    }
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+        finish_group<KP>(thr[g], cnt[g], wave_buf + (int64_t)g * 64 * CAP, p.meta_cnt + (wave * NB + g) * 64,
+                         p.meta_thr + (wave * NB + g) * 64);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Warm-up thresholds for launches whose waves walk the whole table (many queries, K <= 16).  A pass that starts at
+// -inf spends its first thousands of tiles appending and compacting.  This kernel scores a strided sample of
+// n_sample tiles with the same MFMA tiles but keeps no lists: per lane only the M largest tile maxima (M distinct
+// rows of that lane's half of the table).  The two lanes of a query then hold 2 M >= K rows whose coarse score is
+// >= v = min of their M-th values, and the full pass starts from a hair below v.  The value is a heuristic, not a
+// bound the result depends on: the completeness proof of the re-score kernel decides, and a query whose true
+// top-K does not clear the threshold by the coarse error margin is re-run exactly like any other uncertain one.
+template <int NB, int KS, int M>
+__global__ __launch_bounds__(64, 2) void warm_threshold_kernel(CoarseParams p, int n_sample, int tile_stride_tiles,
+                                                               float* __restrict__ out_thr) {
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int qtile = blockIdx.x;
+    short8 bq[NB][KS];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        const int64_t qrow = (int64_t)qtile * 32 * NB + 32 * g + j;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            bq[g][ks] = *reinterpret_cast<const short8*>(p.q_bf16 + qrow * p.dpad + 16 * ks + 8 * h);
+    }
+    float top[NB][M];
+#pragma unroll
+    for (int g = 0; g < NB; ++g)
+#pragma unroll
+        for (int i = 0; i < M; ++i) top[g][i] = kNegInf;
+    const uint16_t* ap = p.t_bf16 + (int64_t)j * p.dpad + 8 * h;
+    const int64_t stride = 32 * (int64_t)p.dpad * tile_stride_tiles;
+    short8 a0[KS], a1[KS];
+    auto load_tile = [&](short8(&dst)[KS], int t) {
+        const uint16_t* src = ap + (int64_t)t * stride;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const short8*>(src + 16 * ks);
+    };
+    auto score_tile = [&](const short8(&a)[KS]) {
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bq[g][ks], acc, 0, 0, 0);
+            float m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+#pragma unroll
+            for (int i = 0; i < M; ++i) {       // insert the tile maximum into the descending list
+                const float hi = fmaxf(top[g][i], m);
+                m = fminf(top[g][i], m);
+                top[g][i] = hi;
+            }
+        }
+    };
+    // sampled tiles are full tiles by construction (the host keeps (n_sample - 1) * stride + 1 <= full tiles)
+    load_tile(a0, 0);
+    int t = 0;
+    for (; t + 2 < n_sample; t += 2) {
+        load_tile(a1, t + 1);
+        score_tile(a0);
+        load_tile(a0, t + 2);
+        score_tile(a1);
+    }
+    score_tile(a0);
+    if (t + 1 < n_sample) {
+        load_tile(a1, t + 1);
+        score_tile(a1);
+    }
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+        float v = top[g][M - 1];
+        v = fminf(v, __shfl_xor(v, 32));
+        if (v > kNegInf) v = v - fabsf(v) * 1e-6f - 1e-30f;
+        if (h == 0) out_thr[(int64_t)qtile * 32 * NB + 32 * g + j] = v;
+    }
+}
+
 // fp32 MFMA: D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) per instruction, k0 on lanes 0-31, k1 on 32-63,
 // so stepping k by 2 reproduces the k-ordered fma chain bit for bit.
 template <int KP, bool EXCL>
@@ -332,6 +593,7 @@ struct RescoreParams {
     int64_t* out_ids;           // (n_q, k)
     float* out_scores;
     int32_t* uncertain;         // (n_q) or null
+    const int* ring_error;      // non-null: a set flag marks every query of the launch uncertain
 };
 
 __device__ __forceinline__ bool ranks_before(float sa, int64_t ia, float sb, int64_t ib) {
@@ -450,6 +712,7 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
             }
             flag = !(kth > tmax + eps);
         }
+        if (p.ring_error != nullptr && *p.ring_error != 0) flag = 1;
         p.uncertain[q] = flag;
     }
 }
@@ -603,6 +866,16 @@ int dpad_for(int64_t d) {
     return p;
 }
 
+// The shared-stream kernel exists for d = 64 (four 16-wide K steps) with four query groups per wave.
+bool ring_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("HMX_TOPK_RING");
+        return e == nullptr || e[0] != '0';
+    }();
+    return on;
+}
+bool ring_shape(bool bf16, int NB, int KS) { return bf16 && NB == 4 && KS == 4 && ring_enabled(); }
+
 bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Plan& pl) {
     if (n_q <= 0 || n_rows <= 0 || d <= 0 || k <= 0 || k > 64 || n_rows >= ((int64_t)1 << 31)) return false;
     if (bf16 && d > 128) return false;
@@ -614,6 +887,7 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
     if (bf16 && pl.KS == 8 && pl.NB == 4) pl.NB = 2;   // d = 128: four query groups would not fit 256 registers
     const int64_t qpw = 32 * pl.NB;   // queries per wave
     pl.chunk = std::min<int64_t>(hmx_ceil_div(n_q, qpw) * qpw, 2048 * qpw);
+    if (ring_shape(bf16, pl.NB, pl.KS)) pl.chunk = hmx_ceil_div(pl.chunk, qpw * kRingWaves) * qpw * kRingWaves;
     pl.n_qtiles = (int)(pl.chunk / (32 * pl.NB));
     int64_t s = hmx_ceil_div(2048, pl.n_qtiles);
     s = std::min<int64_t>(s, 8192 / (2 * pl.KP));              // candidates per query <= 8192
@@ -633,6 +907,17 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
 // re-scored, and the completeness proof there covers what they displaced.
 template <int NB, int KS, int KP>
 void launch_bf16(const CoarseParams& p, hipStream_t s) {
+    if constexpr (NB == 4 && KS == 4) {
+        if (ring_enabled() && p.n_qtiles % kRingWaves == 0 && p.ring_error != nullptr) {
+            constexpr int lds = kStages * kStageBytes;
+            static const hipError_t attr = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&coarse_bf16_ring_kernel<NB, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)attr;
+            hipLaunchKernelGGL((coarse_bf16_ring_kernel<NB, KP>), dim3((p.n_qtiles / kRingWaves) * p.n_splits),
+                               dim3(64 * kRingWaves), lds, s, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((coarse_bf16_kernel<NB, KS, KP>), dim3(p.n_qtiles * p.n_splits), dim3(64), 0, s, p);
 }
 template <int NB, int KS>
@@ -648,6 +933,38 @@ void launch_bf16_ks(const CoarseParams& p, int KS, int KP, hipStream_t s) {
         case 4: launch_bf16_kp<NB, 4>(p, KP, s); break;
         default: launch_bf16_kp<NB, 8>(p, KP, s); break;
     }
+}
+
+bool warm_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("HMX_TOPK_WARM");
+        return e == nullptr || e[0] != '0';
+    }();
+    return on;
+}
+
+template <int NB, int KS>
+void launch_warm_m(int M, const CoarseParams& p, int n_qtiles, int n_sample, int stride_tiles, float* out, hipStream_t s) {
+    if (M <= 5)
+        hipLaunchKernelGGL((warm_threshold_kernel<NB, KS, 5>), dim3(n_qtiles), dim3(64), 0, s, p, n_sample, stride_tiles, out);
+    else
+        hipLaunchKernelGGL((warm_threshold_kernel<NB, KS, 8>), dim3(n_qtiles), dim3(64), 0, s, p, n_sample, stride_tiles, out);
+}
+template <int NB>
+void launch_warm_ks(int KS, int M, const CoarseParams& p, int n_qtiles, int n_sample, int stride_tiles, float* out,
+                    hipStream_t s) {
+    switch (KS) {
+        case 1: launch_warm_m<NB, 1>(M, p, n_qtiles, n_sample, stride_tiles, out, s); break;
+        case 2: launch_warm_m<NB, 2>(M, p, n_qtiles, n_sample, stride_tiles, out, s); break;
+        case 4: launch_warm_m<NB, 4>(M, p, n_qtiles, n_sample, stride_tiles, out, s); break;
+        default: launch_warm_m<NB, 8>(M, p, n_qtiles, n_sample, stride_tiles, out, s); break;
+    }
+}
+void launch_warm(int NB, int KS, int M, const CoarseParams& p, int n_qtiles, int n_sample, int stride_tiles, float* out,
+                 hipStream_t s) {
+    if (NB == 4) launch_warm_ks<4>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s);
+    else if (NB == 2) launch_warm_ks<2>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s);
+    else launch_warm_ks<1>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s);
 }
 
 void launch_rescore(const RescoreParams& r, hipStream_t s) {
@@ -681,7 +998,7 @@ struct TopkPlans {
     int64_t seed_rows[kMaxSeedLevels];
     int n_seed;
     size_t cand_bytes, meta_bytes;
-    size_t total() const { return full.q_bf16_bytes + full.thr_bytes + cand_bytes + 2 * meta_bytes + 1536; }
+    size_t total() const { return full.q_bf16_bytes + full.thr_bytes + cand_bytes + 2 * meta_bytes + 2048; }
 };
 
 bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, TopkPlans& tp) {
@@ -730,12 +1047,16 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
     uint2* cand = ws.take<uint2>(tp.cand_bytes / sizeof(uint2));
     int* meta_cnt = ws.take<int>(tp.meta_bytes / 4);
     float* meta_thr = ws.take<float>(tp.meta_bytes / 4);
+    int* ring_error = ws.take<int>(64);
+    const bool ring = ring_shape(bf16, pl.NB, pl.KS);
+    if (ring && hipMemsetAsync(ring_error, 0, sizeof(int), s) != hipSuccess) return HMX_ELAUNCH;
     const int64_t qpw = 32 * pl.NB;
     const bool excl = exclude != nullptr && n_excl > 0;
 
     for (int64_t q0 = 0; q0 < n_q; q0 += pl.chunk) {
         const int64_t nq = std::min(pl.chunk, n_q - q0);
-        const int n_qtiles = (int)hmx_ceil_div(nq, qpw);
+        int n_qtiles = (int)hmx_ceil_div(nq, qpw);
+        if (ring) n_qtiles = (int)hmx_ceil_div(n_qtiles, kRingWaves) * kRingWaves;   // padded query tiles score zeros
         const int64_t rows_pad = (int64_t)n_qtiles * qpw;
         if (bf16)
             hipLaunchKernelGGL(to_bf16_padded_kernel, dim3((unsigned)std::min<int64_t>(hmx_ceil_div(rows_pad, 16), 8192)),
@@ -760,6 +1081,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             p.n_excl = (int)n_excl;
             p.id_offset = id_offset;
             p.init_thr = thr0;
+            p.ring_error = ring ? ring_error : nullptr;
             p.cand = cand;
             p.meta_cnt = meta_cnt;
             p.meta_thr = meta_thr;
@@ -799,6 +1121,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             r.out_ids = out_ids + q0 * k;
             r.out_scores = out_scores + q0 * k;
             r.uncertain = flags;
+            r.ring_error = ring ? ring_error : nullptr;
             launch_rescore(r, s);
             HMX_CHECK_LAUNCH();
             return HMX_OK;
@@ -813,6 +1136,23 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
                                init_thr);
             HMX_CHECK_LAUNCH();
             thr0 = init_thr;
+        }
+        if (bf16 && tp.n_seed == 0 && pl.KP == 32 && pl.n_splits == 1 && warm_enabled()) {
+            // many queries, every wave walks the whole table: sampled warm-up thresholds (see warm_threshold_kernel)
+            const int64_t full_tiles = n_rows / 32;
+            const int n_sample = (int)std::min<int64_t>(full_tiles / 32, 8192);
+            if (n_sample >= 64) {
+                const int stride_tiles = (int)((full_tiles - 1) / (n_sample - 1));
+                CoarseParams wp{};
+                wp.q_bf16 = q_bf16;
+                wp.t_bf16 = table_bf16;
+                wp.dpad = pl.dpad;
+                void* span = hmx_profile_begin("topk_warm_bf16", s);
+                launch_warm(pl.NB, pl.KS, k <= 10 ? 5 : 8, wp, n_qtiles, n_sample, stride_tiles, init_thr, s);
+                hmx_profile_end(span, s);
+                HMX_CHECK_LAUNCH();
+                thr0 = init_thr;
+            }
         }
         const int rc = pass(pl, n_rows, thr0, uncertain ? uncertain + q0 : nullptr,
                             bf16 ? "topk_coarse_bf16" : "topk_coarse_f32");

@@ -49,7 +49,7 @@ def test_exact_kernel_matches_oracle(nq, rows, d, k):
 
 @pytest.mark.parametrize("nq,rows,d,k", [(5, 3000, 16, 10), (70, 20000, 64, 10), (33, 5001, 60, 50), (1, 64, 64, 10),
                                          (300, 100000, 64, 10), (9, 40000, 128, 50), (5000, 30000, 64, 10),
-                                         (17000, 9000, 32, 10)])
+                                         (17000, 9000, 32, 10), (16500, 40001, 64, 10), (16385, 20011, 64, 50)])
 def test_bf16_path_matches_oracle(nq, rows, d, k):
     q, t = _data(nq, rows, d, 200 + nq)
     ids, sc, st = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), k, return_stats=True)
@@ -126,3 +126,10 @@ def test_full_size_properties():
     assert torch.all(sc[:, :-1] >= sc[:, 1:])
     torch.testing.assert_close(sc, (q[:, None, :] * t[ids]).sum(-1), rtol=1e-4, atol=1e-4)
     assert st["uncertain"] == 0
+    # (4) the many-query launch shape (workgroups of eight waves sharing the item stream) gives the same answer
+    big = torch.cat([q, torch.randn(16500, d, device=DEV, generator=g)])
+    ids_b, sc_b, st_b = ops.score_topk(big, prep, 10, return_stats=True)
+    assert torch.equal(ids_b[:256], ids_e) and torch.equal(sc_b[:256], sc_e)
+    assert torch.all(sc_b[:, :-1] >= sc_b[:, 1:]) and bool((ids_b >= 0).all())
+    torch.testing.assert_close(sc_b, (big[:, None, :] * t[ids_b]).sum(-1), rtol=1e-4, atol=1e-4)
+    assert st_b["uncertain"] == 0
