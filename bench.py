@@ -160,7 +160,7 @@ def run_retrieval(args, world, rank):
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per full 262144-query launch (FETCH_SIZE x 2 + WRITE_SIZE)",
-                     "traffic_source": traffic_src, "kernel": "coarse_bf16_kernel", "launches": k_launches,
+                     "traffic_source": traffic_src, "kernel": "coarse_bf16_ring_kernel", "launches": k_launches,
                      "avg_launch_ms": k_ms / max(k_launches, 1)},
         "uncertain_queries_rerun_exact": uncertain,
     }

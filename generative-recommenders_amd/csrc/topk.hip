@@ -631,7 +631,20 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
                 const int64_t row = p.cand[lane_slot * CAP + e].y;
                 const float* tv = p.t_f32 + row * p.d;
                 float a = 0.f;
-                for (int k = 0; k < p.d; ++k) a = __builtin_fmaf(qv[k], tv[k], a);
+                if ((p.d & 3) == 0 && ((reinterpret_cast<uintptr_t>(tv) | reinterpret_cast<uintptr_t>(qv)) & 15) == 0) {
+                    // same fma chain in k order, operands fetched 16 bytes at a time
+                    const float4* t4 = reinterpret_cast<const float4*>(tv);
+                    const float4* q4 = reinterpret_cast<const float4*>(qv);
+                    for (int k = 0; k < p.d / 4; ++k) {
+                        const float4 x = q4[k], y = t4[k];
+                        a = __builtin_fmaf(x.x, y.x, a);
+                        a = __builtin_fmaf(x.y, y.y, a);
+                        a = __builtin_fmaf(x.z, y.z, a);
+                        a = __builtin_fmaf(x.w, y.w, a);
+                    }
+                } else {
+                    for (int k = 0; k < p.d; ++k) a = __builtin_fmaf(qv[k], tv[k], a);
+                }
                 bool keep = true;
                 if (p.exclude != nullptr) {
                     const int64_t* ex = p.exclude + q * p.n_excl;
