@@ -95,6 +95,23 @@ def test_adversarial_near_duplicates_fall_back_to_exact():
     assert st["uncertain"] > 0
 
 
+def test_many_query_launch_with_planted_rows_and_near_duplicates():
+    """The many-query launch shape (shared item stream, sampled start thresholds) on a table built to stress the
+    start thresholds: every query's best rows are planted scaled copies placed outside and inside the sampled
+    tiles, and a block of near-duplicate rows, larger than the two candidate lists of a query, tops query 0's scores."""
+    g = torch.Generator().manual_seed(17)
+    nq, rows, d = 16400, 70_003, 64
+    t = torch.randn(rows, d, generator=g)
+    q = torch.randn(nq, d, generator=g)
+    spots = torch.randint(1, rows, (nq,), generator=g)
+    q[:8000] = t[spots[:8000]] * 2.5                        # planted winners at random rows
+    dup = q[0] / q[0].norm() * 9.0
+    t[50_000:50_300] = dup + 1e-4 * torch.randn(300, d, generator=g)  # 300 rows the bf16 pass cannot rank (> 2 lists)
+    ids, sc, st = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), 10, return_stats=True)
+    _check(ids, sc, q, t, 10)
+    assert st["uncertain"] >= 1                               # query 0 at least needs the exact pass
+
+
 def test_merge_matches_unsharded():
     q, t = _data(50, 30001, 64, 12)
     full_ids, full_sc = ops.score_topk_exact(q.to(DEV), t.to(DEV), 10)
