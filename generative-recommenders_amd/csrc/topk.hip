@@ -126,7 +126,7 @@ __device__ __forceinline__ void tile_filter(const f32x16& acc, float& thr, int& 
     float m = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-    if (__ballot(m > thr) == 0ull) return;  // wave-uniform fast path
+    if (__builtin_expect(__ballot(m > thr) == 0ull, 1)) return;  // wave-uniform fast path (falls through)
     // keep the sixteen row numbers out of the fast path: without this the compiler computes them before the branch
     asm volatile("" : "+v"(row0));
     uint2* mine = group_buf + (threadIdx.x & 63) * CAP;
