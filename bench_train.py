@@ -41,9 +41,18 @@ def cpu_baseline_train(args, seconds_cap=40.0):
                  bt["act"], bt["dwell"])
     loss.backward()
     dt = time.time() - t0
+    # BASELINE.json configs[0]: encoder forward only (log2feats, eval mode), batch 128, on the same host cores
+    model.eval()
+    be = synth.train_batch(128, args.seq_len, args.users, args.items, "cpu", seed=3)
+    t1 = time.time()
+    with torch.no_grad():
+        model.log2feats(be["seq"], [[] for _ in range(128)], be["tok"], be["ts"], be["act"], be["dwell"])
+    de = time.time() - t1
     return {"value": B / dt, "unit": "user seqs/s", "cores": threads, "kind": "port",
             "sample": f"one fwd+bwd of {B} sequences x {args.seq_len}, same model and tables, PyTorch CPU oracle on "
-                      f"{threads} threads ({dt:.1f} s)"}
+                      f"{threads} threads ({dt:.1f} s)",
+            "encoder_fwd_batch128": {"value": 128 / de, "unit": "user seqs/s",
+                                     "sample": f"log2feats forward of 128 sequences x {args.seq_len}, eval mode ({de:.1f} s)"}}
 
 
 def run_train(args, world, rank, with_cpu_baseline=True):
