@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearParams p) {
     for (int idx = threadIdx.x; idx < npad * KS * 16; idx += 256) {
         const int n = idx / (KS * 16), k = idx % (KS * 16);
         const float v = (n < nc && k < p.K) ? p.W[(int64_t)(n_base + n) * p.w_rs + (int64_t)k * p.w_cs] : 0.f;
-        const uint16_t hi = hmx_f32_to_bf16(v);
+        const uint16_t hi = (uint16_t)hmx_pack_bf16x2(v, 0.f);
         wl[n * KP + k] = hi;
-        if (SPLIT) wl_lo[n * KP + k] = hmx_f32_to_bf16(v - hmx_bf16_to_f32(hi));
+        if (SPLIT) wl_lo[n * KP + k] = (uint16_t)hmx_pack_bf16x2(v - hmx_bf16_to_f32(hi), 0.f);
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -178,13 +178,16 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (ok && k0 + e < p.K) ? xr[k0 + e] : 0.f;
             }
+            uint32_t hw[4], lw[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xv = v[e] * im;
-                const uint16_t hb = hmx_f32_to_bf16(xv);
-                a[ks][e] = (short)hb;
-                if (SPLIT) a_lo[ks][e] = (short)hmx_f32_to_bf16(xv - hmx_bf16_to_f32(hb));
+            for (int e = 0; e < 4; ++e) {      // hardware pair conversion: the operand split costs ~3 ops per element
+                const float x0 = v[2 * e] * im, x1 = v[2 * e + 1] * im;
+                hw[e] = hmx_pack_bf16x2(x0, x1);
+                if (SPLIT)
+                    lw[e] = hmx_pack_bf16x2(x0 - __uint_as_float(hw[e] << 16), x1 - __uint_as_float(hw[e] & 0xffff0000u));
             }
+            a[ks] = __builtin_bit_cast(short8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+            if (SPLIT) a_lo[ks] = __builtin_bit_cast(short8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
         }
         for (int nt = 0; nt < npad / 32; ++nt) {
             f32x16 acc;

@@ -41,3 +41,11 @@ __device__ __forceinline__ uint16_t hmx_f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float hmx_bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// Two fp32 -> two bf16 (round to nearest even) in one v_cvt_pk_bf16_f32; `a` lands in the low half.
+typedef __bf16 hmx_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float hmx_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t hmx_pack_bf16x2(float a, float b) {
+    const hmx_f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hmx_bf16x2_t));
+}
