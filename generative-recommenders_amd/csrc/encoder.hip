@@ -141,7 +141,7 @@ struct LinearParams {
 // SPLIT = true : every operand is split x = hi + lo (two bf16 numbers, 16 significant bits together) and the product
 //                is accumulated as hi*hi + lo*hi + hi*lo on the same MFMA: fp32-class accuracy at three MFMAs.
 template <int KS, bool SPLIT>
-__global__ __launch_bounds__(256) void linear_kernel(LinearParams p) {
+__global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KP = KS * 16 + 8;  // bf16 elements per LDS row (+8 keeps ds_read_b128 conflict-free)
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
