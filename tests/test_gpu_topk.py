@@ -150,3 +150,30 @@ def test_full_size_properties():
     assert torch.all(sc_b[:, :-1] >= sc_b[:, 1:]) and bool((ids_b >= 0).all())
     torch.testing.assert_close(sc_b, (big[:, None, :] * t[ids_b]).sum(-1), rtol=1e-4, atol=1e-4)
     assert st_b["uncertain"] == 0
+
+
+def test_launch_shape_toggles_do_not_change_results(tmp_path):
+    """The shared-stream kernel and the sampled start thresholds are speed features: with either switched off
+    (fresh processes, the switches are read once) ids and scores must be bit-identical to the default path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from generative_recommenders_amd import ops\n"
+        "g = torch.Generator().manual_seed(23)\n"
+        "t = torch.randn(300_001, 64, generator=g).cuda(); q = torch.randn(16500, 64, generator=g).cuda()\n"
+        "ids, sc = ops.score_topk(q, ops.PreparedTable(t), 10)\n"
+        "np.save(sys.argv[1] + '_ids.npy', ids.cpu().numpy()); np.save(sys.argv[1] + '_sc.npy', sc.cpu().numpy())\n")
+    outs = {}
+    for name, env in (("default", {}), ("noring", {"HMX_TOPK_RING": "0"}), ("nowarm", {"HMX_TOPK_WARM": "0"})):
+        e = dict(os.environ)
+        e.update(env)
+        prefix = str(tmp_path / name)
+        subprocess.run([sys.executable, "-c", code, prefix], check=True, env=e, timeout=240)
+        outs[name] = (np.load(prefix + "_ids.npy"), np.load(prefix + "_sc.npy"))
+    for name in ("noring", "nowarm"):
+        assert np.array_equal(outs[name][0], outs["default"][0]), name
+        assert np.array_equal(outs[name][1], outs["default"][1]), name
