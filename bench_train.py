@@ -58,10 +58,12 @@ def cpu_baseline_train(args, seconds_cap=40.0):
 def run_train(args, world, rank, with_cpu_baseline=True):
     from generative_recommenders_amd import hmx, synth
     from generative_recommenders_amd import hydra as H
+    from generative_recommenders_amd import ops as ops_mod
     dev = torch.device("cuda", torch.cuda.current_device())
     B, L, d = args.batch, args.seq_len, args.dim
     model = H.build_model(args.users, args.items, d=d, L=L, dropout=0.2, device=dev, seed=1234)
     model.train()
+    ops_mod.set_fused_table_grad(True)     # table gradients accumulate straight into .grad (same sums, fewer passes)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1)
     bt = synth.train_batch(B, L, args.users, args.items, dev, seed=99 + rank)
     feat = [[] for _ in range(B)]
@@ -146,7 +148,7 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                                 " (configs[4], per GPU)" if (L, d) == (512, 128) else ""),
                    "batch_per_gpu": B, "seq_len": L, "d": d, "users": args.users, "items": args.items,
                    "includes": "zero_grad, forward (encoder + miner top-50 + fused InfoNCE), backward, "
-                               "clip_grad_norm, AdamW",
+                               "clip_grad_norm, AdamW; table gradients accumulated directly into .grad",
                    "parallelism": f"dp{world}" if world > 1 else "single GPU"},
         "fwd_bwd_ms": fwd_bwd_ms, "fwd_bwd_seqs_per_s": B * world / (fwd_bwd_ms * 1e-3), "loss": float(loss.item()),
         "roofline": {"bound": "hbm", "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -38,6 +38,29 @@ def _validate_ids(ids, n_rows, what):
             raise IndexError(f"{what}: index out of range in self (min {lo}, max {hi}, rows {n_rows})")
 
 
+_FUSE_TABLE_GRAD = False
+
+
+def set_fused_table_grad(flag=True):
+    """Opt-in: the backward of the row gathers (and of the fused loss's hard-negative gather) adds straight into
+    `weight.grad` of a leaf table instead of returning a dense (rows, d) tensor for autograd to add.  Same sums in
+    the same order (0 + a + b + ... per row), but one zero-fill per table and step instead of one per gather plus a
+    dense add each (2 GB of traffic per extra gather at 4 M x 64).  Leave it off when gradients are taken with
+    torch.autograd.grad(), which only sees returned values."""
+    global _FUSE_TABLE_GRAD
+    _FUSE_TABLE_GRAD = bool(flag)
+
+
+def _into_param_grad(param):
+    """The tensor a fused table gradient should be added into, or None when the standard path applies."""
+    if not (_FUSE_TABLE_GRAD and isinstance(param, torch.nn.Parameter) and param.is_leaf and param.requires_grad):
+        return None
+    if param.grad is None:
+        param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+    g = param.grad
+    return g if (g.is_contiguous() and g.dtype == torch.float32) else None
+
+
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -73,13 +96,17 @@ class _GatherRows(torch.autograd.Function):
                                                 hmx.ptr(out), hmx.current_stream()), "hmx_gather_rows_f32")
         ctx.save_for_backward(idc)
         ctx.n_rows, ctx.padding_idx = w.shape[0], -1 if padding_idx is None else padding_idx
+        ctx.param = weight
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (idc,) = ctx.saved_tensors
-        gw = scatter_add_rows(grad_out, idc, ctx.n_rows, ctx.padding_idx) if ctx.needs_input_grad[0] else None
-        return gw, None, None
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        acc = _into_param_grad(ctx.param)
+        gw = scatter_add_rows(grad_out, idc, ctx.n_rows, ctx.padding_idx, out=acc)
+        return (None if acc is not None else gw), None, None
 
 
 def gather_rows(weight, ids, padding_idx=None):
@@ -113,14 +140,21 @@ class _GatherRouted(torch.autograd.Function):
                                                   hmx.current_stream()), "hmx_gather_routed_f32")
         ctx.save_for_backward(idc, tt)
         ctx.rows = (iw.shape[0], uw.shape[0])
+        ctx.params = (item_w, user_w)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         idc, tt = ctx.saved_tensors
-        gi = scatter_add_rows(grad_out, idc, ctx.rows[0], 0, tt, 1) if ctx.needs_input_grad[0] else None
-        gu = scatter_add_rows(grad_out, idc, ctx.rows[1], 0, tt, 2) if ctx.needs_input_grad[1] else None
-        return gi, gu, None, None
+        grads = []
+        for which in (0, 1):
+            if not ctx.needs_input_grad[which]:
+                grads.append(None)
+                continue
+            acc = _into_param_grad(ctx.params[which])
+            g = scatter_add_rows(grad_out, idc, ctx.rows[which], 0, tt, which + 1, out=acc)
+            grads.append(None if acc is not None else g)
+        return grads[0], grads[1], None, None
 
 
 def gather_routed(item_weight, user_weight, ids, token_type):
@@ -151,6 +185,7 @@ class _FusedNCE(torch.autograd.Function):
                                             hmx.ptr(k_inv), hmx.current_stream()), "hmx_nce_fwd_f32")
         ctx.save_for_backward(q, k, tab, hid, iid, logits, lse, q_inv, k_inv)
         ctx.cfg = (float(temperature), int(bool(normalize)), n_rows, n_hard, n_inb)
+        ctx.table_param = table
         return row_loss
 
     @staticmethod
@@ -162,9 +197,16 @@ class _FusedNCE(torch.autograd.Function):
         g = _f32c(grad_rows)
         dq, dk = torch.empty_like(q), torch.empty_like(k)
         want_table = n_hard > 0 and ctx.needs_input_grad[2]
-        # the hard-negative rows always receive their sums (the kernel has one code path); without a table
-        # gradient wanted, n_hard = 0 is passed for the key-gradient half by handing no destination
-        dtable = torch.zeros(n_rows, d, dtype=torch.float32, device=dev) if n_hard > 0 else None
+        # The kernel needs a destination that is zero on entry (it normalises the touched rows in place).  With
+        # fused table gradients on and no gradient accumulated yet, that destination is the table's own .grad,
+        # created here (this backward runs before the gathers' backward, the loss being the last op of forward).
+        fused_dst = None
+        if want_table and _FUSE_TABLE_GRAD and isinstance(ctx.table_param, torch.nn.Parameter) \
+                and ctx.table_param.is_leaf and ctx.table_param.grad is None:
+            fused_dst = _into_param_grad(ctx.table_param)
+        dtable = fused_dst
+        if dtable is None and n_hard > 0:
+            dtable = torch.zeros(n_rows, d, dtype=torch.float32, device=dev)
         L = hmx.lib()
         ws = workspace(L.hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb), dev)
         coef = logits   # overwritten with the key-gradient coefficients: backward may run once
@@ -173,7 +215,7 @@ class _FusedNCE(torch.autograd.Function):
                                     hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq), hmx.ptr(dk),
                                     hmx.ptr(dtable), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
                   "hmx_nce_bwd_f32")
-        return dq, dk, (dtable if want_table else None), None, None, None, None
+        return dq, dk, (dtable if (want_table and fused_dst is None) else None), None, None, None, None
 
 
 def fused_nce_rows(q, k, table, hard_ids, inb_idx, temperature=0.05, normalize=True):

@@ -183,6 +183,33 @@ def test_train_step_against_reference_golden():
     assert float(m.shared_embeddings.item_emb.weight.grad[0].abs().sum()) == 0.0
 
 
+def test_fused_table_gradients_are_bit_identical_to_autograd_accumulation():
+    """ops.set_fused_table_grad(True) adds the gathers' and the loss's table gradients straight into .grad; every
+    parameter gradient of a train step must come out bit-identical to the standard autograd path (same RNG seed)."""
+    from generative_recommenders_amd import ops
+    s, p = G.load("g10_train"), "G10_train_small"
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    grads = []
+    try:
+        for fused in (False, True):
+            ops.set_fused_table_grad(fused)
+            m = _model_from(s, p, dropout=0.0).train()
+            torch.manual_seed(0)
+            loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, feat, feat, feat, b["ts"], b["act"],
+                     b["dwell"])
+            loss.backward()
+            grads.append({k: (None if q.grad is None else q.grad.clone()) for k, q in m.named_parameters()})
+    finally:
+        ops.set_fused_table_grad(False)
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        a, c = grads[0][k], grads[1][k]
+        assert (a is None) == (c is None), k
+        if a is not None:
+            assert torch.equal(a, c), k
+
+
 def test_log2feats_and_grads_vs_oracle_benchmark_shape():
     """d = 64, L = 100 (the benchmark model), B = 6 with ragged left padding; eval mode."""
     from generative_recommenders_amd import synth
