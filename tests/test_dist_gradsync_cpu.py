@@ -39,12 +39,23 @@ def _data():
     return torch.randint(0, 500, (64,), generator=g)
 
 
-def _worker(rank, world, port, out_dir):
+def _torch_row_ops():
+    """CPU stand-ins for the HIP gather / scatter-add (same contract: ids < 0 are ignored)."""
+    def gather(table, ids):
+        return table[ids]
+
+    def scatter_add(rows, ids, out):
+        keep = ids >= 0
+        out.index_add_(0, ids[keep], rows[keep])
+    return gather, scatter_add
+
+
+def _worker(rank, world, port, out_dir, sparse=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model = _Toy(seed=100 + rank)           # different init per rank: broadcast must fix that
     broadcast_parameters(model, src=0)
-    sync = GradientSync(model, big_bytes=500 * 8 * 4)
+    sync = GradientSync(model, big_bytes=500 * 8 * 4, sparse_tables=sparse, row_ops=_torch_row_ops() if sparse else None)
     assert [tuple(p.shape) for p in sync.big] == [(500, 8)] and len(sync.small) == 3
     ids = _data()[rank * 32:(rank + 1) * 32]
     for _ in range(2):                      # second pass reuses the flat bucket
@@ -55,8 +66,12 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_whole_batch(tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+import pytest
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_two_rank_gradients_equal_whole_batch(tmp_path, sparse):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), sparse), nprocs=2, join=True)
     ref = _Toy(seed=100)
     ids = _data()
     # mean over ranks of per-rank mean losses == mean over the whole batch (equal halves); the extra term is on
@@ -66,6 +81,8 @@ def test_two_rank_gradients_equal_whole_batch(tmp_path):
         got = torch.load(tmp_path / f"g{r}.pt", weights_only=True)
         for k, p in ref.named_parameters():
             assert torch.allclose(got[k], p.grad, rtol=1e-5, atol=1e-6), k
+    a, b = (torch.load(tmp_path / f"g{r}.pt", weights_only=True) for r in range(2))
+    assert all(torch.equal(a[k], b[k]) for k in a)          # every rank ends with the same bits
 
 
 def test_single_process_is_a_no_op():
