@@ -29,6 +29,7 @@ namespace {
 
 using short8 = __attribute__((ext_vector_type(8))) short;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 
 constexpr float kNegInf = -INFINITY;
 constexpr int kRoom = 16;  // free slots guaranteed before a tile's epilogue (one lane sees 16 scores per tile)
@@ -77,6 +78,7 @@ template <int KP>
 __device__ __forceinline__ void compact_list(uint2* buf, int n, int& new_cnt, float& new_thr, float old_thr) {
     constexpr int CAP = cap_for(KP), EPL = CAP / 64;
     const int lane = threadIdx.x & 63;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's appends (buffer stores) have reached memory
     float s[EPL];
     unsigned id[EPL];
     int rank[EPL];
@@ -123,15 +125,28 @@ template <int KP, bool EXCL>
 __device__ __forceinline__ void tile_filter(const f32x16& acc, float& thr, int& cnt, uint2* group_buf, int row0,
                                             const CoarseParams& p, int64_t q_global) {
     constexpr int CAP = cap_for(KP);
-    float m = kNegInf;   // starting from a constant keeps the chain at eight v_max3 (no operand canonicalisation)
+    // Maximum of the sixteen scores as a tree of v_max3 over five triples (+ register 15): the same eight
+    // instructions as a chain, and the slow path can tell from the triple maxima which registers to look at.
+    float t[5];
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(m, acc[r]), acc[r + 1]);
+    for (int g = 0; g < 5; ++g) t[g] = fmaxf(fmaxf(acc[3 * g], acc[3 * g + 1]), acc[3 * g + 2]);
+    const float m = fmaxf(fmaxf(fmaxf(t[0], t[1]), acc[15]), fmaxf(fmaxf(t[2], t[3]), t[4]));
     if (__builtin_expect(__ballot(m > thr) == 0ull, 1)) return;  // wave-uniform fast path (falls through)
     // keep the sixteen row numbers out of the fast path: without this the compiler computes them before the branch
     asm volatile("" : "+v"(row0));
-    uint2* mine = group_buf + (threadIdx.x & 63) * CAP;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    // Appends go through a buffer descriptor built from the wave-uniform list base: scalar base + 32-bit lane
+    // offset, so no per-lane 64-bit pointer has to stay live (or be spilled and reloaded) around the MFMA loop.
+    const uint64_t gb = reinterpret_cast<uint64_t>(group_buf);   // wave-uniform by contract; say so to the compiler
+    void* list_base = reinterpret_cast<void*>(
+        ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(gb >> 32)) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane((int)gb));
+    const auto lists = __builtin_amdgcn_make_buffer_rsrc(list_base, 0, 64 * CAP * (int)sizeof(uint2), 0x00020000);
+    // lane number recomputed here (two mbcnt) behind an opaque zero, so that nothing is carried through the hot loop
+    int opaque_zero = 0;
+    asm volatile("" : "+v"(opaque_zero));
+    const int lane_off = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)opaque_zero)) *
+                         CAP * (int)sizeof(uint2);
+    auto append_row = [&](int r) {   // registers in ascending order = rows in ascending order within a lane
         const int row = row0 + (r & 3) + 8 * (r >> 2);
         bool pass = acc[r] > thr;
         if (EXCL) {
@@ -141,11 +156,24 @@ __device__ __forceinline__ void tile_filter(const f32x16& acc, float& thr, int& 
                 for (int e = 0; e < p.n_excl; ++e) pass = pass && (ex[e] != gid);
             }
         }
-        if (pass) {
-            mine[cnt] = make_uint2(__float_as_uint(acc[r]), (unsigned)row);
-            ++cnt;
+        // no branch and no exec juggling per row: a lane whose row fails stores at an offset beyond the
+        // descriptor's range, which the buffer range check drops
+        u32x2 entry;
+        entry[0] = __float_as_uint(acc[r]);
+        entry[1] = (unsigned)row;
+        const int off = pass ? lane_off + cnt * (int)sizeof(uint2) : (int)0x80000000;
+        __builtin_amdgcn_raw_buffer_store_b64(entry, lists, off, 0, 0);
+        cnt += pass ? 1 : 0;
+    };
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        if (__ballot(t[g] > thr) != 0ull) {   // wave-uniform: usually one triple of the five holds the hit
+            append_row(3 * g);
+            append_row(3 * g + 1);
+            append_row(3 * g + 2);
         }
     }
+    if (__ballot(acc[15] > thr) != 0ull) append_row(15);
     unsigned long long need = __ballot(cnt > CAP - kRoom);
     while (need) {
         const int o = __ffsll((long long)need) - 1;
@@ -308,14 +336,21 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     __shared__ int ready[kStages];   // generation (stage / kStages + 1) of the data in each slot
     __shared__ int done[kStages];    // waves that finished with the slot, summed over generations
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: list pointers stay in scalar registers
     const int n_wg_tiles = p.n_qtiles / kRingWaves;
     const int wg_tile = blockIdx.x % n_wg_tiles, split = blockIdx.x / n_wg_tiles;
     const int qtile = wg_tile * kRingWaves + w;
     const int64_t wave = (int64_t)qtile * p.n_splits + split;
     const int64_t row_begin = (int64_t)split * p.rows_per_split;
     const int64_t row_end = min(row_begin + p.rows_per_split, p.n_rows);
-    uint2* wave_buf = p.cand + wave * NB * 64 * CAP;
+    // the list base is wave-uniform; held in scalar registers it costs no VGPRs and is never spilled
+    uint2* wave_buf;
+    {
+        const uint64_t wb = reinterpret_cast<uint64_t>(p.cand + wave * NB * 64 * CAP);
+        wave_buf = reinterpret_cast<uint2*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(wb >> 32)) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane((int)wb));
+    }
     if (tid < kStages) {
         ready[tid] = 0;
         done[tid] = 0;
@@ -356,21 +391,27 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
         }
     };
+    // The ring's ordering needs no cache maintenance: data and counters live in LDS, which serves the waves of a
+    // workgroup in issue order.  What it needs is (1) the DMA's LDS writes complete before the generation counter
+    // moves (vmcnt), (2) a wave's fragment reads complete before it retires the slot (lgkmcnt), and (3) the
+    // compiler not moving LDS accesses across the counter operations (the "memory" clobbers).  A release fence
+    // would also wait for the wave's outstanding candidate stores to be acknowledged by memory, every stage.
     auto publish = [&](int s) {   // after the stage's DMA has landed
-        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): every DMA of this wave has written LDS
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA of this wave has written LDS
         if (lane == 0) __hip_atomic_store(&ready[s % kStages], s / kStages + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto wait_at_least = [&](int* flag, int target) {
         int spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        // wave-uniform poll: one lane's view of the counter decides for the wave (scalar compare and branch)
+        while (__builtin_amdgcn_readfirstlane(
+                   __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > kRingSpinLimit) {
                 if (lane == 0) *p.ring_error = 1;
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        asm volatile("" ::: "memory");
     };
     const int n_full_stages = n_rows_here / (kStageTiles * 32);   // stages whose 128 rows all exist
     int pending = -1;
@@ -389,7 +430,7 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
             publish(pending);
             pending = -1;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's LDS reads of the slot are complete
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the slot are complete
         if (lane == 0) __hip_atomic_fetch_add(&done[c % kStages], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // A fragments of tile tl of a stage image: row tl * 32 + j, logical chunk 2 ks + h, swizzled by (row & 7) = (j & 7)
@@ -423,28 +464,64 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
         fetch_stage(w, w >= n_full_stages);
         publish(w);
     }
-    // Full stages, four tiles each, software-pipelined: the LDS reads of the next tile are issued before the
-    // MFMAs of the current one (two fragment buffers), also across the stage boundary.
-    short8 a0[KS], a1[KS];
+    // Full stages, four tiles each, software-pipelined inside the wave over two accumulator sets: while the MFMAs of
+    // tile t fill one set, the filter walks the other set (tile t - 1), one query group per MFMA quarter, and the
+    // fragment register a quarter has just consumed is reloaded with the next tile's.  The vector work of the
+    // filter then issues in the shadow of the matrix pipe instead of after it.  The idle set starts at -inf, so
+    // the first step's filter passes nothing.
+    short8 a0[KS];
     if (n_full_stages > 0) {
+        f32x16 accA[NB], accB[NB];
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) accB[g][q] = kNegInf;
+        auto step = [&](f32x16(&cur)[NB], const f32x16(&prev)[NB], const char* next_frag, int prev_t) {
+            const int prev_row0 = (int)row_begin + 32 * prev_t + 4 * h;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+                    if (ks == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) z[q] = 0.f;
+                        cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[g][ks], z, 0, 0, 0);
+                    } else {
+                        cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[g][ks], cur[g], 0, 0, 0);
+                    }
+                }
+                a0[ks] = *reinterpret_cast<const short8*>(next_frag + a_off[ks]);
+                // KS == NB: quarter ks filters query group ks of the previous tile
+                tile_filter<KP, false>(prev[ks], thr[ks], cnt[ks], wave_buf + ks * 64 * CAP, prev_row0, p, 0);
+            }
+        };
+        static_assert(KS == NB, "one filter group per MFMA quarter");
         enter_stage(0);
         read_tile(a0, smem, 0);
-    }
-    for (int c = 0; c < n_full_stages; ++c) {
-        const char* img = smem + (c % kStages) * kStageBytes;
-        const int t = c * kStageTiles;
-        read_tile(a1, img, 1);
-        compute_tile(a0, t, false);
-        read_tile(a0, img, 2);
-        compute_tile(a1, t + 1, false);
-        read_tile(a1, img, 3);
-        compute_tile(a0, t + 2, false);
-        if (c + 1 < n_full_stages) {
-            enter_stage(c + 1);
-            read_tile(a0, smem + ((c + 1) % kStages) * kStageBytes, 0);
+        for (int c = 0; c < n_full_stages; ++c) {
+            const char* img = smem + (c % kStages) * kStageBytes;
+            const int t = c * kStageTiles;
+#ifdef HMX_RING_PRIO
+            if ((c ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+            step(accA, accB, img + 4096, t - 1);
+            step(accB, accA, img + 8192, t);
+            step(accA, accB, img + 12288, t + 1);
+            // fragments of this stage's last tile are in registers: retire the slot, take the next stage
+            const char* next = img + 12288;               // no next full stage: re-read this tile (unused)
+            if (c + 1 < n_full_stages) {
+                leave_stage(c);
+                enter_stage(c + 1);
+                next = smem + ((c + 1) % kStages) * kStageBytes;
+            }
+            step(accB, accA, next, t + 2);
         }
-        compute_tile(a1, t + 3, false);
-        leave_stage(c);
+        leave_stage(n_full_stages - 1);
+        const int last_row0 = (int)row_begin + 32 * (n_full_stages * kStageTiles - 1) + 4 * h;
+#pragma unroll
+        for (int g = 0; g < NB; ++g)
+            tile_filter<KP, false>(accB[g], thr[g], cnt[g], wave_buf + g * 64 * CAP, last_row0, p, 0);
     }
     if (n_full_stages < n_stages) {       // the last, short stage: plain read-then-compute
         const int c = n_full_stages;
