@@ -469,7 +469,8 @@ struct ScanParams {
     const float* D;      // (C)
     int B, L, C, ED, H;
     float* yg;           // (T, C)
-    float* hs;           // (T, C, 16) or null (states kept for the backward pass)
+    float* hs;           // (T, 4, C, 4) or null: states kept for the backward pass, state n of channel c at
+                         // [t][n / 4][c][n % 4], so that one 16-byte store per lane writes whole cache lines per wave
 };
 
 constexpr int kScanChunk = 64;  // time steps of dbc staged per LDS fill
@@ -497,9 +498,17 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
         for (int idx = threadIdx.x; idx < steps * HP; idx += 256) rows[idx] = p.dbc[(seq * p.L + tc0) * HP + idx];
         __syncthreads();
         if (!live) continue;
+        // x and z of the next step are requested while this step computes (unconditional, clamped at the chunk end)
+        float nx = p.xc[(seq * p.L + tc0) * p.C + c];
+        float nz = p.xz ? p.xz[(seq * p.L + tc0) * p.C + c] : 0.f;
         for (int s = 0; s < steps; ++s) {
             const int64_t row = seq * p.L + tc0 + s;
-            const float x = p.xc[row * p.C + c];
+            const float x = nx, zv = nz;
+            {
+                const int64_t rn = seq * p.L + tc0 + min(s + 1, steps - 1);
+                nx = p.xc[rn * p.C + c];
+                nz = p.xz ? p.xz[rn * p.C + c] : 0.f;
+            }
             const float* r = rows + s * HP + hh * kP;
             float dpre = 0.f;
 #pragma unroll
@@ -513,11 +522,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
                 y += h[n] * r[kR + kN + n];
             }
             if (p.hs) {
-                float4* dst = reinterpret_cast<float4*>(p.hs + (row * p.C + c) * kN);
+                float4* dst = reinterpret_cast<float4*>(p.hs) + row * 4 * p.C + c;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dst[q] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+                for (int q = 0; q < 4; ++q)
+                    dst[(int64_t)q * p.C] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
             }
-            p.yg[row * p.C + c] = (y + Dv * x) * (p.xz ? silu_(p.xz[row * p.C + c]) : 1.f);
+            p.yg[row * p.C + c] = (y + Dv * x) * (p.xz ? silu_(zv) : 1.f);
         }
     }
 }
@@ -593,21 +603,31 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(ScanBwdParams q) {
         for (int idx = threadIdx.x; idx < steps * HP; idx += 256) rows[idx] = p.dbc[(seq * p.L + tc0) * HP + idx];
         __syncthreads();
         if (!live) continue;
+        // The step's global operands (saved state, x, z, dy) are requested one step ahead: the loads of step s - 1
+        // are in flight while step s computes.  The last step of a chunk re-requests its own row (unconditional
+        // loads keep the compiler's wait counts from serialising the pipeline).
+        float4 nh[4];
+        float nx, nz, ngy;
+        auto request = [&](int s_req) {
+            const int64_t rr = seq * p.L + tc0 + s_req;
+            const float4* src = reinterpret_cast<const float4*>(p.hs) + rr * 4 * p.C + c;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) nh[k4] = src[(int64_t)k4 * p.C];
+            nx = p.xc[rr * p.C + c];
+            nz = p.xz ? p.xz[rr * p.C + c] : 0.f;
+            ngy = q.dyg[rr * p.C + c];
+        };
+        request(steps - 1);
         for (int s = steps - 1; s >= 0; --s) {
             const int64_t row = seq * p.L + tc0 + s;
-            const float x = p.xc[row * p.C + c];
-            const float z = p.xz ? p.xz[row * p.C + c] : 0.f;
-            const float gy = q.dyg[row * p.C + c];
+            const float x = nx, z = nz, gy = ngy;
             const float* r = rows + s * HP + hh * kP;
             float hcur[kN];
-            {
-                const float4* src = reinterpret_cast<const float4*>(p.hs + (row * p.C + c) * kN);
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const float4 v = src[k4];
-                    hcur[4 * k4] = v.x; hcur[4 * k4 + 1] = v.y; hcur[4 * k4 + 2] = v.z; hcur[4 * k4 + 3] = v.w;
-                }
+            for (int k4 = 0; k4 < 4; ++k4) {
+                hcur[4 * k4] = nh[k4].x; hcur[4 * k4 + 1] = nh[k4].y; hcur[4 * k4 + 2] = nh[k4].z; hcur[4 * k4 + 3] = nh[k4].w;
             }
+            request(max(s - 1, 0));
             float dpre = 0.f;
 #pragma unroll
             for (int k = 0; k < kR; ++k) dpre += Wd[k] * r[k];

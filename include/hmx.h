@@ -235,8 +235,9 @@ int hmx_pscan_bwd(const float* A, const float* H, const float* dH, int64_t B, in
 
 /* Selective scan of all heads (hydra3.py:107-123, 203-214) fused with the dt projection + softplus
  * (:210) and the SiLU(z) gate (:273).  C = H * ED channels, ED a power of two >= 32, state N = 16,
- * dt rank 16.  dbc (T, H, 48) = [dt_rank | B | C] rows of deltaBC_layer.  hs (T, C, 16), if not NULL,
- * receives every state for the backward pass.  Backward writes dxc, dz, per-group partials of d(dbc)
+ * dt rank 16.  dbc (T, H, 48) = [dt_rank | B | C] rows of deltaBC_layer.  hs (T * C * 16 floats), if not NULL,
+ * receives every state for the backward pass in the kernels' own order ([t][n / 4][c][n % 4]: opaque to callers,
+ * to be handed to hmx_scan_bwd unchanged).  Backward writes dxc, dz, per-group partials of d(dbc)
  * shaped (T, H, hmx_scan_groups_per_head(ED), 48) (sum with hmx_sum_groups_f32) and per-sequence
  * parameter partials par_part (B, C, 34) = [dA_log(16) | dW_dt(16) | db_dt | dD]. */
 int hmx_scan_fwd(const float* xc, const float* z, const float* dbc, const float* Wdt, const float* bdt,
