@@ -492,11 +492,12 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
                     }
                 }
                 a0[ks] = *reinterpret_cast<const short8*>(next_frag + a_off[ks]);
-                // KS == NB: quarter ks filters query group ks of the previous tile
-                tile_filter<KP, false>(prev[ks], thr[ks], cnt[ks], wave_buf + ks * 64 * CAP, prev_row0, p, 0);
+                // quarter ks filters query group ks of the previous tile (NB <= KS groups)
+                if (ks < NB)
+                    tile_filter<KP, false>(prev[ks], thr[ks], cnt[ks], wave_buf + ks * 64 * CAP, prev_row0, p, 0);
             }
         };
-        static_assert(KS == NB, "one filter group per MFMA quarter");
+        static_assert(NB <= KS, "at most one filter group per MFMA quarter");
         enter_stage(0);
         read_tile(a0, smem, 0);
         for (int c = 0; c < n_full_stages; ++c) {
@@ -722,16 +723,21 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
                 } else {
                     for (int k = 0; k < p.d; ++k) a = __builtin_fmaf(qv[k], tv[k], a);
                 }
-                bool keep = true;
-                if (p.exclude != nullptr) {
-                    const int64_t* ex = p.exclude + q * p.n_excl;
-                    for (int x = 0; x < p.n_excl; ++x) keep = keep && (ex[x] != row + p.id_offset);
-                }
-                if (keep) {
-                    sc[i] = a;
-                    id[i] = row + p.id_offset;
-                }
+                sc[i] = a;
+                id[i] = row + p.id_offset;
             }
+        }
+    }
+    if (p.exclude != nullptr && q_ok) {   // drop shortlisted rows that are on the query's exclusion list
+        const int64_t* ex = p.exclude + q * p.n_excl;
+        for (int x = 0; x < p.n_excl; ++x) {
+            const int64_t gone = ex[x];
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+                if (id[i] == gone) {
+                    sc[i] = kNegInf;
+                    id[i] = kNoId;
+                }
         }
     }
     // largest coarse threshold of any lane that served this query
@@ -964,7 +970,14 @@ bool ring_enabled() {
     }();
     return on;
 }
-bool ring_shape(bool bf16, int NB, int KS) { return bf16 && NB == 4 && KS == 4 && ring_enabled(); }
+// With fewer than four query groups per wave (few queries) a workgroup's eight waves cover only 256 or 512 queries,
+// so the shared stream needs at least 512 queries to fill its waves, and a pass over a short table prefix (the
+// seeding passes) is left to the independent-wave kernel.
+constexpr int64_t kRingMinRowsFewQueries = 1 << 18;
+bool ring_shape(bool bf16, int NB, int KS, int64_t n_q) {
+    return bf16 && KS == 4 && ring_enabled() && (NB == 4 || n_q >= 512);
+}
+bool ring_pass(int NB, int64_t rows) { return NB == 4 || rows >= kRingMinRowsFewQueries; }
 
 bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Plan& pl) {
     if (n_q <= 0 || n_rows <= 0 || d <= 0 || k <= 0 || k > 64 || n_rows >= ((int64_t)1 << 31)) return false;
@@ -977,11 +990,11 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
     if (bf16 && pl.KS == 8 && pl.NB == 4) pl.NB = 2;   // d = 128: four query groups would not fit 256 registers
     const int64_t qpw = 32 * pl.NB;   // queries per wave
     pl.chunk = std::min<int64_t>(hmx_ceil_div(n_q, qpw) * qpw, 2048 * qpw);
-    if (ring_shape(bf16, pl.NB, pl.KS)) pl.chunk = hmx_ceil_div(pl.chunk, qpw * kRingWaves) * qpw * kRingWaves;
+    if (ring_shape(bf16, pl.NB, pl.KS, n_q)) pl.chunk = hmx_ceil_div(pl.chunk, qpw * kRingWaves) * qpw * kRingWaves;
     pl.n_qtiles = (int)(pl.chunk / (32 * pl.NB));
     int64_t s = hmx_ceil_div(2048, pl.n_qtiles);
     s = std::min<int64_t>(s, 8192 / (2 * pl.KP));              // candidates per query <= 8192
-    s = std::min<int64_t>(s, std::max<int64_t>(1, n_rows / 2048));
+    s = std::min<int64_t>(s, std::max<int64_t>(1, n_rows / 256));     // at least eight tiles per wave
     if (s >= 8) s = s / 8 * 8;                                  // XCD-aware block mapping wants a multiple of 8
     pl.n_splits = (int)std::max<int64_t>(1, s);
     pl.rows_per_split = hmx_ceil_div(hmx_ceil_div(n_rows, pl.n_splits), 32) * 32;
@@ -997,7 +1010,7 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
 // re-scored, and the completeness proof there covers what they displaced.
 template <int NB, int KS, int KP>
 void launch_bf16(const CoarseParams& p, hipStream_t s) {
-    if constexpr (NB == 4 && KS == 4) {
+    if constexpr (KS == 4) {
         if (ring_enabled() && p.n_qtiles % kRingWaves == 0 && p.ring_error != nullptr) {
             constexpr int lds = kStages * kStageBytes;
             static const hipError_t attr = hipFuncSetAttribute(
@@ -1101,7 +1114,11 @@ bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, To
     // splits): there the cold start is most of a wave's life.  With >= 64 K queries per launch each wave walks
     // the whole table and the extra re-score passes cost more than the cold start they remove.
     int64_t rows[kMaxSeedLevels];
-    const int n = tp.full.n_splits >= 8 ? seed_levels(n_rows, rows) : 0;
+    static const bool seed_on = [] {
+        const char* e = getenv("HMX_TOPK_SEED");
+        return e == nullptr || e[0] != '0';
+    }();
+    const int n = (tp.full.n_splits >= 8 && seed_on) ? seed_levels(n_rows, rows) : 0;
     for (int i = 0; i < n; ++i) {
         Plan ps;
         if (!make_plan(n_q, rows[i], d, k, true, ps) || ps.chunk != tp.full.chunk) {
@@ -1138,7 +1155,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
     int* meta_cnt = ws.take<int>(tp.meta_bytes / 4);
     float* meta_thr = ws.take<float>(tp.meta_bytes / 4);
     int* ring_error = ws.take<int>(64);
-    const bool ring = ring_shape(bf16, pl.NB, pl.KS);
+    const bool ring = ring_shape(bf16, pl.NB, pl.KS, n_q);
     if (ring && hipMemsetAsync(ring_error, 0, sizeof(int), s) != hipSuccess) return HMX_ELAUNCH;
     const int64_t qpw = 32 * pl.NB;
     const bool excl = exclude != nullptr && n_excl > 0;
@@ -1171,7 +1188,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             p.n_excl = (int)n_excl;
             p.id_offset = id_offset;
             p.init_thr = thr0;
-            p.ring_error = ring ? ring_error : nullptr;
+            p.ring_error = (ring && ring_pass(plan.NB, rows)) ? ring_error : nullptr;
             p.cand = cand;
             p.meta_cnt = meta_cnt;
             p.meta_thr = meta_thr;
@@ -1211,7 +1228,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             r.out_ids = out_ids + q0 * k;
             r.out_scores = out_scores + q0 * k;
             r.uncertain = flags;
-            r.ring_error = ring ? ring_error : nullptr;
+            r.ring_error = (ring && ring_pass(plan.NB, rows)) ? ring_error : nullptr;
             launch_rescore(r, s);
             HMX_CHECK_LAUNCH();
             return HMX_OK;

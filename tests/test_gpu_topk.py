@@ -112,6 +112,24 @@ def test_many_query_launch_with_planted_rows_and_near_duplicates():
     assert st["uncertain"] >= 1                               # query 0 at least needs the exact pass
 
 
+@pytest.mark.parametrize("nq,rows,k,with_excl", [(1024, 300_017, 50, True), (640, 262_144, 10, False),
+                                                 (4100, 270_001, 10, False), (4096, 262_200, 50, True)])
+def test_few_query_shared_stream_shapes(nq, rows, k, with_excl):
+    """Few queries over a long table (the hard-negative miner's shape): workgroups of eight waves with one or two
+    query groups per wave share the item stream, after the seeding passes over the table prefixes."""
+    q, t = _data(nq, rows, 64, 300 + nq)
+    excl = None
+    if with_excl:
+        g = torch.Generator().manual_seed(31)
+        excl = torch.randint(0, rows, (nq, 20), generator=g)
+        top = torch.from_numpy(C.score_topk(q[:64].numpy(), t.numpy(), 5, None, 0)[0])
+        excl[:64, :5] = top                                     # knock out true winners of the first queries
+    ids, sc, st = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), k,
+                                 None if excl is None else excl.to(DEV), return_stats=True)
+    _check(ids, sc, q, t, k, excl)
+    assert st["uncertain"] <= nq // 10 + 1
+
+
 def test_merge_matches_unsharded():
     q, t = _data(50, 30001, 64, 12)
     full_ids, full_sc = ops.score_topk_exact(q.to(DEV), t.to(DEV), 10)
