@@ -115,6 +115,44 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ P
     if (w == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// Two-stage form for tall inputs: block (cb, r) sums the rows of chunk r for 64 columns into part[r][c]; the second
+// stage adds the chunks in order.  Same fixed order on every run.
+__global__ __launch_bounds__(256) void colsum_chunks_kernel(const float* __restrict__ P, int64_t rows, int64_t cols,
+                                                            int64_t ld, int64_t rows_per_chunk, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(r0 + rows_per_chunk, rows);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int64_t r = r0 + w;
+        for (; r + 12 < r1; r += 16) {   // four independent loads in flight per lane
+            s0 += P[r * ld + c];
+            s1 += P[(r + 4) * ld + c];
+            s2 += P[(r + 8) * ld + c];
+            s3 += P[(r + 12) * ld + c];
+        }
+        for (; r < r1; r += 4) s0 += P[r * ld + c];
+    }
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int n_chunks, int64_t cols,
+                                                            float* __restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < n_chunks; ++r) s += part[(int64_t)r * cols + c];
+    out[c] = s;
+}
+// chunks of rows so that about a thousand blocks run; none when the input is short
+int colsum_chunks(int64_t rows, int64_t cols) {
+    const int64_t col_blocks = hmx_ceil_div(cols, 64);
+    const int64_t want = std::max<int64_t>(1, 1024 / col_blocks);
+    return (int)std::min<int64_t>(want, std::max<int64_t>(1, rows / 64));
+}
+
 // ---------------------------------------------------------------------------- linear (bf16 MFMA)
 struct LinearParams {
     const float* X;
@@ -735,10 +773,31 @@ extern "C" int hmx_rmsnorm_bwd(const float* x, const float* scale, const float* 
     return HMX_OK;
 }
 
-extern "C" int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_t ld, float* out, void* stream) {
+extern "C" size_t hmx_colsum_workspace_bytes(int64_t rows, int64_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int n = colsum_chunks(rows, cols);
+    return n > 1 ? (size_t)n * (size_t)cols * sizeof(float) : 0;
+}
+
+extern "C" int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_t ld, float* out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
     HMX_ENTER();
     if (cols == 0) return HMX_OK;
     if (!P || !out || rows < 0 || ld < cols) return HMX_EINVAL;
+    const int n = colsum_chunks(rows, cols);
+    if (n > 1 && workspace != nullptr) {
+        if (workspace_bytes < hmx_colsum_workspace_bytes(rows, cols)) return HMX_EWORKSPACE;
+        float* part = static_cast<float*>(workspace);
+        const int64_t rpc = hmx_ceil_div(hmx_ceil_div(rows, n), 4) * 4;
+        const int n_used = (int)hmx_ceil_div(rows, rpc);
+        hipLaunchKernelGGL(colsum_chunks_kernel, dim3((unsigned)hmx_ceil_div(cols, 64), (unsigned)n_used), dim3(256), 0,
+                           (hipStream_t)stream, P, rows, cols, ld, rpc, part);
+        HMX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)hmx_ceil_div(cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                           part, n_used, cols, out);
+        HMX_CHECK_LAUNCH();
+        return HMX_OK;
+    }
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)hmx_ceil_div(cols, 64)), dim3(256), 0, (hipStream_t)stream, P, rows,
                        cols, ld, out);
     HMX_CHECK_LAUNCH();

@@ -31,7 +31,10 @@ def colsum(P):
     P = _f32c(P)
     rows, cols = P.shape
     out = _empty(cols, like=P)
-    hmx.check(_L().hmx_colsum_f32(hmx.ptr(P), rows, cols, cols, hmx.ptr(out), _s()), "hmx_colsum_f32")
+    nbytes = _L().hmx_colsum_workspace_bytes(rows, cols)
+    ws = workspace(nbytes, P.device) if nbytes else None
+    hmx.check(_L().hmx_colsum_f32(hmx.ptr(P), rows, cols, cols, hmx.ptr(out), hmx.ptr(ws), nbytes, _s()),
+              "hmx_colsum_f32")
     return out
 
 

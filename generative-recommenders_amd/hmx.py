@@ -38,7 +38,8 @@ PROTOTYPES = {
     "hmx_rmsnorm_fwd": (c_int, [P, P, I64, I64, F, P, P, P]),
     "hmx_rmsnorm_bwd_blocks": (I64, [I64]),
     "hmx_rmsnorm_bwd": (c_int, [P, P, P, P, I64, I64, P, P, P]),
-    "hmx_colsum_f32": (c_int, [P, I64, I64, I64, P, P]),
+    "hmx_colsum_workspace_bytes": (c_size_t, [I64, I64]),
+    "hmx_colsum_f32": (c_int, [P, I64, I64, I64, P, P, c_size_t, P]),
     "hmx_set_linear_precision": (c_int, [c_int]),
     "hmx_linear_f32": (c_int, [P, I64, P, I64, I64, P, I64, I64, I64, P, I64, P, I64, F, P, I64, F, P, P, c_int, P]),
     "hmx_linear_wgrad_workspace_bytes": (c_size_t, [I64, I64, I64]),

@@ -158,8 +158,12 @@ int64_t hmx_rmsnorm_bwd_blocks(int64_t T);
 int hmx_rmsnorm_bwd(const float* x, const float* scale, const float* rstd, const float* dy, int64_t T, int64_t d,
                     float* dx, float* dscale_part, void* stream);
 
-/* out[c] = sum_r P[r * ld + c], fixed summation order (reduction of per-block / per-sequence partials). */
-int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_t ld, float* out, void* stream);
+/* out[c] = sum_r P[r * ld + c], fixed summation order (reduction of per-block / per-sequence partials).
+ * With a workspace of hmx_colsum_workspace_bytes(rows, cols) tall inputs are summed in row chunks by many
+ * workgroups and the chunks added in order; workspace NULL: one workgroup per 64 columns. */
+size_t hmx_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_t ld, float* out, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* Dense projection on bf16 MFMA with fp32 accumulate (nn.Linear / F.linear at hydra3.py:206,210,263,
  * 275,366,388,416-418,643 and their dgrad):
