@@ -168,6 +168,16 @@ def test_full_size_properties():
     assert torch.all(sc_b[:, :-1] >= sc_b[:, 1:]) and bool((ids_b >= 0).all())
     torch.testing.assert_close(sc_b, (big[:, None, :] * t[ids_b]).sum(-1), rtol=1e-4, atol=1e-4)
     assert st_b["uncertain"] == 0
+    # (5) the hard-negative miner's shape: 1024 queries, top-50, positives + history excluded (seeding passes over the
+    # table prefixes, then eight-wave workgroups with one query group per wave)
+    qm = torch.randn(1024, d, device=DEV, generator=g)
+    excl = torch.randint(1, rows, (1024, 200), device=DEV, generator=g)
+    excl[:, :10] = ops.score_topk_exact(qm, t, 10)[0]           # the true top-10 are on every query's list
+    ids_m, sc_m, st_m = ops.score_topk(qm, prep, 50, excl, return_stats=True)
+    ids_x, sc_x = ops.score_topk_exact(qm, t, 50, excl)
+    assert torch.equal(ids_m, ids_x) and torch.equal(sc_m, sc_x)
+    assert not bool((ids_m[:, :, None] == excl[:, None, :10]).any())
+    assert st_m["uncertain"] <= 8
 
 
 def test_launch_shape_toggles_do_not_change_results(tmp_path):
