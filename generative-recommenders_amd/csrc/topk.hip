@@ -678,12 +678,14 @@ __device__ __forceinline__ bool ranks_before(float sa, int64_t ia, float sb, int
     return sa > sb || (sa == sb && ia < ib);
 }
 
+// (four waves per SIMD = at most 128 registers: with 1024 one-query workgroups a fourth resident workgroup per CU is a
+// whole round of the launch)
 template <int TPQ, int CPT>
-__global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
+__global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p) {
     constexpr int QPB = 256 / TPQ;
     constexpr int64_t kNoId = 0x7fffffffffffffffll;
-    __shared__ float sh_s[4];
-    __shared__ int64_t sh_i[4];
+    __shared__ float sh_s[2][4];     // two copies, used by alternate selection rounds: one barrier per round
+    __shared__ int64_t sh_i[2][4];
     const int t = threadIdx.x % TPQ;
     const int64_t q = (int64_t)blockIdx.x * QPB + threadIdx.x / TPQ;
     const bool q_ok = q < p.n_q;
@@ -728,29 +730,28 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
             }
         }
     }
-    if (p.exclude != nullptr && q_ok) {   // drop shortlisted rows that are on the query's exclusion list
-        const int64_t* ex = p.exclude + q * p.n_excl;
-        for (int x = 0; x < p.n_excl; ++x) {
-            const int64_t gone = ex[x];
-#pragma unroll
-            for (int i = 0; i < CPT; ++i)
-                if (id[i] == gone) {
-                    sc[i] = kNegInf;
-                    id[i] = kNoId;
-                }
-        }
-    }
     // largest coarse threshold of any lane that served this query
     for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
     if (TPQ == 256) {
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) sh_s[threadIdx.x >> 6] = tmax;
+        if ((threadIdx.x & 63) == 0) sh_s[0][threadIdx.x >> 6] = tmax;
         __syncthreads();
-        tmax = fmaxf(fmaxf(sh_s[0], sh_s[1]), fmaxf(sh_s[2], sh_s[3]));
+        tmax = fmaxf(fmaxf(sh_s[0][0], sh_s[0][1]), fmaxf(sh_s[0][2], sh_s[0][3]));
         __syncthreads();
     }
+    // Exclusion lists are applied lazily: only the row that wins a round is looked up; an excluded winner is dropped
+    // and the round repeated (every repeat removes a candidate, so the loop ends).  The first 256 entries of the list
+    // are staged in LDS; each wave looks the winner up by itself (four entries per lane): all waves of a query reach the same
+    // verdict without a barrier.
+    const int64_t* ex = (p.exclude != nullptr && q_ok) ? p.exclude + q * p.n_excl : nullptr;
+    const int lane = threadIdx.x & 63;
+    __shared__ int64_t sh_ex[QPB][256];
+    int64_t* my_ex = sh_ex[threadIdx.x / TPQ];
+    for (int x = t; x < 256; x += TPQ) my_ex[x] = (ex != nullptr && x < p.n_excl) ? ex[x] : kNoId;
+    __syncthreads();
     float kth = kNegInf;
-    for (int r = 0; r < p.k; ++r) {
+    int round = 0;
+    for (int r = 0; r < p.k; ++round) {
         float bs = sc[0];
         int64_t bi = id[0];
 #pragma unroll
@@ -768,20 +769,21 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
             }
         }
         if (TPQ == 256) {
+            // A wave that is one round ahead writes the other copy; it cannot be two ahead (the barrier below).
+            const int pb = round & 1;
             if ((threadIdx.x & 63) == 0) {
-                sh_s[threadIdx.x >> 6] = bs;
-                sh_i[threadIdx.x >> 6] = bi;
+                sh_s[pb][threadIdx.x >> 6] = bs;
+                sh_i[pb][threadIdx.x >> 6] = bi;
             }
             __syncthreads();
-            bs = sh_s[0];
-            bi = sh_i[0];
+            bs = sh_s[pb][0];
+            bi = sh_i[pb][0];
 #pragma unroll
             for (int w = 1; w < 4; ++w)
-                if (ranks_before(sh_s[w], sh_i[w], bs, bi)) {
-                    bs = sh_s[w];
-                    bi = sh_i[w];
+                if (ranks_before(sh_s[pb][w], sh_i[pb][w], bs, bi)) {
+                    bs = sh_s[pb][w];
+                    bi = sh_i[pb][w];
                 }
-            __syncthreads();
         }
         const bool found = bi != kNoId;
 #pragma unroll
@@ -790,11 +792,18 @@ __global__ __launch_bounds__(256) void rescore_select_kernel(RescoreParams p) {
                 sc[i] = kNegInf;
                 id[i] = kNoId;
             }
+        int gone = 0;
+        if (found && ex != nullptr) {
+            gone = (my_ex[lane] == bi || my_ex[lane + 64] == bi || my_ex[lane + 128] == bi || my_ex[lane + 192] == bi) ? 1 : 0;
+            for (int x = lane + 256; x < p.n_excl; x += 64) gone |= (ex[x] == bi) ? 1 : 0;
+        }
+        if (__ballot(gone != 0) != 0ull) continue;          // wave-local verdict, identical in every wave of the query
         if (q_ok && t == 0) {
             p.out_ids[q * p.k + r] = found ? bi : -1;
             p.out_scores[q * p.k + r] = found ? bs : kNegInf;
         }
         kth = found ? bs : kNegInf;
+        ++r;
     }
     if (p.uncertain != nullptr && q_ok && t == 0) {
         int flag = 0;
