@@ -171,6 +171,10 @@ def run_retrieval(args, world, rank):
 
 def main():
     args = parse()
+    if os.environ.get("HMX_BENCH_WATCHDOG"):
+        # diagnostics: dump every thread's Python stack and exit if the run is still going after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["HMX_BENCH_WATCHDOG"]), exit=True)
     world, rank, _ = setup_dist(args.gpus)
     workload = args.workload
     if workload == "auto":
