@@ -677,15 +677,20 @@ struct RescoreParams {
 __device__ __forceinline__ bool ranks_before(float sa, int64_t ia, float sb, int64_t ib) {
     return sa > sb || (sa == sb && ia < ib);
 }
+__device__ __forceinline__ bool ranks_before(float sa, unsigned ia, float sb, unsigned ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
 
 // (four waves per SIMD = at most 128 registers: with 1024 one-query workgroups a fourth resident workgroup per CU is a
 // whole round of the launch)
 template <int TPQ, int CPT>
 __global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p) {
     constexpr int QPB = 256 / TPQ;
+    // rows are handled as 32-bit local row numbers (order by row == order by id: ids are row + id_offset)
+    constexpr unsigned kNoRow = 0xffffffffu;
     constexpr int64_t kNoId = 0x7fffffffffffffffll;
     __shared__ float sh_s[2][4];     // two copies, used by alternate selection rounds: one barrier per round
-    __shared__ int64_t sh_i[2][4];
+    __shared__ unsigned sh_i[2][4];
     const int t = threadIdx.x % TPQ;
     const int64_t q = (int64_t)blockIdx.x * QPB + threadIdx.x / TPQ;
     const bool q_ok = q < p.n_q;
@@ -695,38 +700,106 @@ __global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p)
     const float* qv = p.q_f32 + (q_ok ? q : 0) * p.d;
 
     float sc[CPT];
-    int64_t id[CPT];
+    unsigned id[CPT];
     float tmax = kNegInf;
+    auto exact_score = [&](int64_t row) {
+        const float* tv = p.t_f32 + row * p.d;
+        float a = 0.f;
+        if ((p.d & 3) == 0 && ((reinterpret_cast<uintptr_t>(tv) | reinterpret_cast<uintptr_t>(qv)) & 15) == 0) {
+            // same fma chain in k order, operands fetched 16 bytes at a time
+            const float4* t4 = reinterpret_cast<const float4*>(tv);
+            const float4* q4 = reinterpret_cast<const float4*>(qv);
+            int k = 0;
+            // four 16-byte pieces of the row (and of the query) are requested together: one memory latency per 64
+            // bytes instead of one per 16 (the chain itself stays sequential)
+            for (; k + 4 <= p.d / 4; k += 4) {
+                float4 y[4], x[4];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        const int c = t + TPQ * i;
-        sc[i] = kNegInf;
-        id[i] = kNoId;
-        if (q_ok && c < n_cand) {
-            const int split = c / (2 * p.KP), hh = (c / p.KP) & 1, e = c % p.KP;
-            const int64_t wave = (int64_t)qtile * p.n_splits + split;
-            const int64_t lane_slot = (wave * p.NB + g) * 64 + jq + 32 * hh;
-            if (e == 0) tmax = fmaxf(tmax, p.meta_thr[lane_slot]);
-            if (e < p.meta_cnt[lane_slot]) {
-                const int64_t row = p.cand[lane_slot * CAP + e].y;
-                const float* tv = p.t_f32 + row * p.d;
-                float a = 0.f;
-                if ((p.d & 3) == 0 && ((reinterpret_cast<uintptr_t>(tv) | reinterpret_cast<uintptr_t>(qv)) & 15) == 0) {
-                    // same fma chain in k order, operands fetched 16 bytes at a time
-                    const float4* t4 = reinterpret_cast<const float4*>(tv);
-                    const float4* q4 = reinterpret_cast<const float4*>(qv);
-                    for (int k = 0; k < p.d / 4; ++k) {
-                        const float4 x = q4[k], y = t4[k];
-                        a = __builtin_fmaf(x.x, y.x, a);
-                        a = __builtin_fmaf(x.y, y.y, a);
-                        a = __builtin_fmaf(x.z, y.z, a);
-                        a = __builtin_fmaf(x.w, y.w, a);
-                    }
-                } else {
-                    for (int k = 0; k < p.d; ++k) a = __builtin_fmaf(qv[k], tv[k], a);
+                for (int u = 0; u < 4; ++u) y[u] = t4[k + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = q4[k + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a = __builtin_fmaf(x[u].x, y[u].x, a);
+                    a = __builtin_fmaf(x[u].y, y[u].y, a);
+                    a = __builtin_fmaf(x[u].z, y[u].z, a);
+                    a = __builtin_fmaf(x[u].w, y[u].w, a);
                 }
-                sc[i] = a;
-                id[i] = row + p.id_offset;
+            }
+            for (; k < p.d / 4; ++k) {
+                const float4 x = q4[k], y = t4[k];
+                a = __builtin_fmaf(x.x, y.x, a);
+                a = __builtin_fmaf(x.y, y.y, a);
+                a = __builtin_fmaf(x.z, y.z, a);
+                a = __builtin_fmaf(x.w, y.w, a);
+            }
+        } else {
+            for (int k = 0; k < p.d; ++k) a = __builtin_fmaf(qv[k], tv[k], a);
+        }
+        return a;
+    };
+    auto slot_of_list = [&](int list) {   // list = 2 * split + row half
+        const int64_t wave = (int64_t)qtile * p.n_splits + (list >> 1);
+        return (wave * p.NB + g) * 64 + jq + 32 * (list & 1);
+    };
+    if constexpr (TPQ == 256) {
+        // One query per workgroup, up to 256 lists that are mostly short: the entries are numbered consecutively
+        // (exclusive prefix of the list lengths) and dealt to the threads round-robin, so every lane re-scores about
+        // the same number of rows whatever the lengths are.
+        __shared__ int sh_off[257];
+        __shared__ int sh_wave_total[4];
+        const int n_lists = p.n_splits * 2;
+        int len = 0;
+        if (q_ok && t < n_lists) {
+            const int64_t ls = slot_of_list(t);
+            len = min(p.meta_cnt[ls], p.KP);
+            tmax = p.meta_thr[ls];
+        }
+        int incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if ((t & 63) >= off) incl += up;
+        }
+        if ((t & 63) == 63) sh_wave_total[t >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (t >> 6); ++w) base += sh_wave_total[w];
+        sh_off[t + 1] = base + incl;
+        if (t == 0) sh_off[0] = 0;
+        __syncthreads();
+        const int n_valid = sh_off[256];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int jv = t + 256 * i;
+            sc[i] = kNegInf;
+            id[i] = kNoRow;
+            if (jv < n_valid) {
+                int lo = 0, hi = n_lists - 1;          // largest list with sh_off[list] <= jv
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (sh_off[mid] <= jv) lo = mid; else hi = mid - 1;
+                }
+                const int64_t row = p.cand[slot_of_list(lo) * CAP + (jv - sh_off[lo])].y;
+                sc[i] = exact_score(row);
+                id[i] = (unsigned)row;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = t + TPQ * i;
+            sc[i] = kNegInf;
+            id[i] = kNoRow;
+            if (q_ok && c < n_cand) {
+                const int list = c / p.KP, e = c % p.KP;
+                const int64_t lane_slot = slot_of_list(list);
+                if (e == 0) tmax = fmaxf(tmax, p.meta_thr[lane_slot]);
+                if (e < p.meta_cnt[lane_slot]) {
+                    const int64_t row = p.cand[lane_slot * CAP + e].y;
+                    sc[i] = exact_score(row);
+                    id[i] = (unsigned)row;
+                }
             }
         }
     }
@@ -751,18 +824,27 @@ __global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p)
     __syncthreads();
     float kth = kNegInf;
     int round = 0;
-    for (int r = 0; r < p.k; ++round) {
-        float bs = sc[0];
-        int64_t bi = id[0];
+    // Each thread caches the best of its own CPT slots; a round only re-reduces the cached values, and only the wave
+    // that owned the winner clears it and rescans (ids are unique within a query: the lists cover disjoint rows).
+    float lbs;
+    unsigned lbi;
+    auto rescan = [&]() {
+        lbs = sc[0];
+        lbi = id[0];
 #pragma unroll
         for (int i = 1; i < CPT; ++i)
-            if (ranks_before(sc[i], id[i], bs, bi)) {
-                bs = sc[i];
-                bi = id[i];
+            if (ranks_before(sc[i], id[i], lbs, lbi)) {
+                lbs = sc[i];
+                lbi = id[i];
             }
+    };
+    rescan();
+    for (int r = 0; r < p.k; ++round) {
+        float bs = lbs;
+        unsigned bi = lbi;
         for (int off = 32; off > 0; off >>= 1) {
             const float os = __shfl_xor(bs, off);
-            const int64_t oi = __shfl_xor(bi, off);
+            const unsigned oi = (unsigned)__shfl_xor((int)bi, off);
             if (ranks_before(os, oi, bs, bi)) {
                 bs = os;
                 bi = oi;
@@ -785,21 +867,28 @@ __global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p)
                     bi = sh_i[pb][w];
                 }
         }
-        const bool found = bi != kNoId;
+        const bool found = bi != kNoRow;
+        const int64_t gid = (int64_t)bi + p.id_offset;
+        const bool mine = found && lbi == bi;
+        if (__ballot(mine) != 0ull) {   // wave-uniform: the winner sat in this wave
+            if (mine) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i)
-            if (found && id[i] == bi) {
-                sc[i] = kNegInf;
-                id[i] = kNoId;
+                for (int i = 0; i < CPT; ++i)
+                    if (id[i] == bi) {
+                        sc[i] = kNegInf;
+                        id[i] = kNoRow;
+                    }
+                rescan();
             }
+        }
         int gone = 0;
         if (found && ex != nullptr) {
-            gone = (my_ex[lane] == bi || my_ex[lane + 64] == bi || my_ex[lane + 128] == bi || my_ex[lane + 192] == bi) ? 1 : 0;
-            for (int x = lane + 256; x < p.n_excl; x += 64) gone |= (ex[x] == bi) ? 1 : 0;
+            gone = (my_ex[lane] == gid || my_ex[lane + 64] == gid || my_ex[lane + 128] == gid || my_ex[lane + 192] == gid) ? 1 : 0;
+            for (int x = lane + 256; x < p.n_excl; x += 64) gone |= (ex[x] == gid) ? 1 : 0;
         }
         if (__ballot(gone != 0) != 0ull) continue;          // wave-local verdict, identical in every wave of the query
         if (q_ok && t == 0) {
-            p.out_ids[q * p.k + r] = found ? bi : -1;
+            p.out_ids[q * p.k + r] = found ? gid : -1;
             p.out_scores[q * p.k + r] = found ? bs : kNegInf;
         }
         kth = found ? bs : kNegInf;
