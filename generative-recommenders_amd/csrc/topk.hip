@@ -1183,13 +1183,15 @@ void launch_rescore(const RescoreParams& r, hipStream_t s) {
 }
 
 // Threshold seeding for the bf16 pass.  A pass that starts with thresholds at -inf spends its first tiles
-// appending every score and compacting every list; so the table prefixes of 256, 4096 and 65536 rows are scored
-// first, each seeded with the exact top-K of the one before.  Only the 256-row pass starts cold; every later pass
-// sees about K * (growth factor) scores above its starting thresholds per query.
-constexpr int kMaxSeedLevels = 3;
-int seed_levels(int64_t n_rows, int64_t* sample_rows) {
+// appending every score and compacting every list; so growing table prefixes are scored first, each seeded with
+// the exact top-K of the one before.  The first prefix is 2 * KP rows: each of a query's two lanes then sees exactly
+// KP rows, which fit its list without a single compaction (a cold pass over 256 rows at KP = 64 took 0.5 ms, all of
+// it in the end-of-pass compactions; over 128 rows it takes 8 us).  Every later pass sees about 16 K scores above
+// its starting thresholds per query.
+constexpr int kMaxSeedLevels = 4;
+int seed_levels(int64_t n_rows, int KP, int64_t* sample_rows) {
     int n = 0;
-    for (int64_t r = 256; r <= 65536 && r * 8 <= n_rows; r *= 16) sample_rows[n++] = r;
+    for (int64_t r = 2 * KP; n < kMaxSeedLevels && r <= 524288 && r * 4 <= n_rows; r *= 16) sample_rows[n++] = r;
     return n;
 }
 
@@ -1216,7 +1218,7 @@ bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, To
         const char* e = getenv("HMX_TOPK_SEED");
         return e == nullptr || e[0] != '0';
     }();
-    const int n = (tp.full.n_splits >= 8 && seed_on) ? seed_levels(n_rows, rows) : 0;
+    const int n = (tp.full.n_splits >= 8 && seed_on) ? seed_levels(n_rows, tp.full.KP, rows) : 0;
     for (int i = 0; i < n; ++i) {
         Plan ps;
         if (!make_plan(n_q, rows[i], d, k, true, ps) || ps.chunk != tp.full.chunk) {
