@@ -6,10 +6,15 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "hmx_common.h"
+
+#ifndef HMX_PLAIN_IN_FLIGHT
+#define HMX_PLAIN_IN_FLIGHT 16
+#endif
 
 namespace hmx_seg {
 namespace {   // internal linkage: every translation unit that includes this header gets its own kernels
@@ -38,7 +43,7 @@ __device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
 // value(entry) = rows[entry]: the plain scatter-add of materialised gradient rows
 struct PlainRows {
     using Val = uint32_t;               // what travels with the key through the sort: the entry number
-    static constexpr int kInFlight = 4; // entries summed per trip of the run loop
+    static constexpr int kInFlight = HMX_PLAIN_IN_FLIGHT; // entries requested per trip of the run loop (summed in order)
     static constexpr int kPiece = 512;  // the sorted array is also cut every kPiece entries
     static constexpr bool kBalanced = false;   // one group per run start (summation order fixed by the contract)
     const float* rows;
@@ -111,7 +116,11 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(Src src, const int64_
 constexpr int kChunk = 8;
 constexpr int kSuper = 512;
 
-template <int VEC, class Src>
+// WIDE: trips of Src::kInFlight entries with all keys requested up front, for inputs whose runs are long (a small
+// table hit by many ids: the trip is three dependent memory latencies deep, so depth is what counts); otherwise
+// trips of four with the key loads stopping at the run's end, which costs the least registers and loads when
+// most runs are one or two entries long.  The additions happen in entry order either way: same bits.
+template <int VEC, class Src, bool WIDE>
 __global__ __launch_bounds__(kBlock) void segment_sum_kernel(Src src,
                                                              const uint32_t* __restrict__ skeys,
                                                              const typename Src::Val* __restrict__ svals, int64_t n, int cpr,
@@ -143,16 +152,27 @@ __global__ __launch_bounds__(kBlock) void segment_sum_kernel(Src src,
             for (int c = lane_c; c < cpr; c += lpr) {
                 V acc = vzero<VEC>();
                 int64_t e = j;
-                constexpr int U = Src::kInFlight;
-                while (true) {
+                auto trip = [&](auto width) -> bool {
+                    constexpr int U = decltype(width)::value;
                     bool m[U];
                     typename Src::Val sv[U];
                     V v[U];
                     bool run = true;
+                    if constexpr (WIDE) {
+                        uint32_t kk[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        run = run && (e + u < blk_end) && (skeys[e + u] == key);
-                        m[u] = run;
+                        for (int u = 0; u < U; ++u) kk[u] = skeys[(e + u < blk_end) ? e + u : blk_end - 1];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            run = run && (e + u < blk_end) && (kk[u] == key);
+                            m[u] = run;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            run = run && (e + u < blk_end) && (skeys[e + u] == key);
+                            m[u] = run;
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u)
@@ -166,8 +186,16 @@ __global__ __launch_bounds__(kBlock) void segment_sum_kernel(Src src,
                             vadd(acc, v[u]);
                             e_end = e + u + 1;
                         }
-                    if (!m[U - 1]) break;
+                    if (!m[U - 1]) return false;
                     e += U;
+                    return true;
+                };
+                if constexpr (WIDE) {
+                    while (trip(std::integral_constant<int, Src::kInFlight>{})) {
+                    }
+                } else {
+                    while (trip(std::integral_constant<int, 4>{})) {
+                    }
                 }
                 {
                     const bool ends_true = (e_end == n) || skeys[e_end] != key;
@@ -386,13 +414,18 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
     const int64_t groups = Src::kBalanced ? n_sb : hmx_ceil_div(n, kChunk);
     const int grid3 = (int)std::min<int64_t>(hmx_ceil_div(groups, kBlock >> l2), (int64_t)kMaxGrid * 4);
     const int grid4 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid);
+    const bool long_runs = n >= 8 * n_rows;   // on average eight or more entries per table row
     if (vec) {
         if constexpr (Src::kBalanced)
             hipLaunchKernelGGL((segment_sum_balanced_kernel<4, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys,
                                svals, n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
         else
-            hipLaunchKernelGGL((segment_sum_kernel<4, Src>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals, n,
-                               (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+            if (long_runs)
+                hipLaunchKernelGGL((segment_sum_kernel<4, Src, true>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
+                                   n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+            else
+                hipLaunchKernelGGL((segment_sum_kernel<4, Src, false>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
+                                   n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
         hipLaunchKernelGGL((segment_join_kernel<4, SB>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
                            sentinel, table, head_piece, tail_piece);
     } else {
@@ -400,8 +433,12 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
             hipLaunchKernelGGL((segment_sum_balanced_kernel<1, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys,
                                svals, n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
         else
-            hipLaunchKernelGGL((segment_sum_kernel<1, Src>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals, n,
-                               (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+            if (long_runs)
+                hipLaunchKernelGGL((segment_sum_kernel<1, Src, true>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
+                                   n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+            else
+                hipLaunchKernelGGL((segment_sum_kernel<1, Src, false>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
+                                   n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
         hipLaunchKernelGGL((segment_join_kernel<1, SB>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
                            sentinel, table, head_piece, tail_piece);
     }
