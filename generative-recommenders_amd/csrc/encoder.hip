@@ -518,15 +518,26 @@ __global__ __launch_bounds__(256) void conv_silu_bwd_kernel(const float* __restr
     float x0 = X(L - 4), x1 = X(L - 3), x2 = X(L - 2), x3 = X(L - 1);  // x[t-3..t]
     float du1 = 0.f, du2 = 0.f, du3 = 0.f;                             // du[t+1..t+3]
     float dw0 = 0.f, dw1 = 0.f, dw2 = 0.f, dw3 = 0.f, db = 0.f;
-    for (int t = L - 1; t >= 0; --t) {
+    auto one_step = [&](int t, float g, float x_new) {
         const float u = bb + (((w0 * x0) + w1 * x1) + w2 * x2) + w3 * x3;
-        const float du = dxc[(seq * L + t) * C + c] * silu_grad_(u);
+        const float du = g * silu_grad_(u);
         dw0 += du * x0; dw1 += du * x1; dw2 += du * x2; dw3 += du * x3;
         db += du;
         dxz[(seq * L + t) * C + c] = w3 * du + w2 * du1 + w1 * du2 + w0 * du3;
         du3 = du2; du2 = du1; du1 = du;
-        x3 = x2; x2 = x1; x1 = x0; x0 = X(t - 4);
+        x3 = x2; x2 = x1; x1 = x0; x0 = x_new;
+    };
+    int t = L - 1;
+    for (; t >= 3; t -= 4) {   // four steps per trip: their eight loads are requested together, the steps stay in order
+        float g[4], xn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = dxc[(seq * L + t - k) * C + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xn[k] = X(t - 4 - k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) one_step(t - k, g[k], xn[k]);
     }
+    for (; t >= 0; --t) one_step(t, dxc[(seq * L + t) * C + c], X(t - 4));
     float* o = part + (seq * C + c) * 5;
     o[0] = dw0; o[1] = dw1; o[2] = dw2; o[3] = dw3; o[4] = db;
 }
