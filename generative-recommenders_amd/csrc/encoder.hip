@@ -290,10 +290,11 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgradParams p) {
     const bool n_ok = n < p.N;
     const int kind = kc < p.K ? 0 : ((kc == p.K && p.with_bias) ? 1 : 2);
     int64_t t = t0;
-    for (; t + 8 <= t1; t += 8) {   // four MFMA steps per trip, their eight loads issued together
-        float a[4], b[4];
+    constexpr int kSteps = 16;      // MFMA steps per trip; their 2 * kSteps loads are issued together
+    for (; t + 2 * kSteps <= t1; t += 2 * kSteps) {
+        float a[kSteps], b[kSteps];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kSteps; ++u) {
             const int64_t tt = t + 2 * u + h;
             a[u] = n_ok ? p.dY[tt * p.ldy + n] : 0.f;
             b[u] = kind == 1 ? 1.f : 0.f;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgradParams p) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        for (int u = 0; u < kSteps; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
     for (; t < t1; t += 2) {
         const int64_t tt = t + h;
