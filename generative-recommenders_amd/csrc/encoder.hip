@@ -227,6 +227,15 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
             a[ks] = __builtin_bit_cast(short8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
             if (SPLIT) a_lo[ks] = __builtin_bit_cast(short8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
         }
+        // Roles: weights are the MFMA row operand, tokens the column operand, so a lane owns ONE token (column i) and
+        // sixteen outputs n = nt * 32 + 8 * q + 4 * h + (0..3), q = 0..3: four 16-byte stores per tile instead of sixteen
+        // 4-byte ones, with bias and residuals read 16 bytes at a time as well.
+        const int64_t tt = tile * 32 + i;
+        const bool t_ok = tt < p.T;
+        const float om = (t_ok && p.out_rowmask) ? p.out_rowmask[tt] : 1.f;
+        const bool vec_ok = ((p.ldy | p.ldr1 | p.ldr2) & 3) == 0 &&
+                            ((reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.R1) |
+                              reinterpret_cast<uintptr_t>(p.R2) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
         for (int nt = 0; nt < npad / 32; ++nt) {
             f32x16 acc;
 #pragma unroll
@@ -237,25 +246,49 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
                 const short8 b = *reinterpret_cast<const short8*>(wl + off);
                 if (SPLIT) {
                     const short8 b_lo = *reinterpret_cast<const short8*>(wl_lo + off);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[ks], b, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b_lo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a_lo[ks], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a[ks], acc, 0, 0, 0);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a[ks], acc, 0, 0, 0);
             }
-            const int n = n_base + nt * 32 + i;
-            if (n < n_base + nc) {
-                const float bv = p.bias ? p.bias[n] : 0.f;
+            if (!t_ok) continue;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t tt = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (tt < p.T) {
-                        float v = acc[r] + bv;
-                        if (p.R1) v += p.c1 * p.R1[tt * p.ldr1 + n];
-                        if (p.R2) v += p.c2 * p.R2[tt * p.ldr2 + n];
-                        if (p.out_rowmask) v *= p.out_rowmask[tt];
-                        float* dst = p.Y + tt * p.ldy + n;
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = n_base + nt * 32 + 8 * q + 4 * h;
+                if (n0 >= n_base + nc) continue;
+                float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                float* dst = p.Y + tt * p.ldy + n0;
+                if (vec_ok && n0 + 4 <= n_base + nc && (n0 & 3) == 0) {
+                    if (p.bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0);
+                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    }
+                    if (p.R1) {
+                        const float4 rv = *reinterpret_cast<const float4*>(p.R1 + tt * p.ldr1 + n0);
+                        v[0] += p.c1 * rv.x; v[1] += p.c1 * rv.y; v[2] += p.c1 * rv.z; v[3] += p.c1 * rv.w;
+                    }
+                    if (p.R2) {
+                        const float4 rv = *reinterpret_cast<const float4*>(p.R2 + tt * p.ldr2 + n0);
+                        v[0] += p.c2 * rv.x; v[1] += p.c2 * rv.y; v[2] += p.c2 * rv.z; v[3] += p.c2 * rv.w;
+                    }
+                    if (p.out_rowmask) { v[0] *= om; v[1] *= om; v[2] *= om; v[3] *= om; }
+                    if (p.accumulate) {
+                        const float4 cur = *reinterpret_cast<const float4*>(dst);
+                        v[0] += cur.x; v[1] += cur.y; v[2] += cur.z; v[3] += cur.w;
+                    }
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = n0 + e;
+                        if (n < n_base + nc) {
+                            float x = v[e] + (p.bias ? p.bias[n] : 0.f);
+                            if (p.R1) x += p.c1 * p.R1[tt * p.ldr1 + n];
+                            if (p.R2) x += p.c2 * p.R2[tt * p.ldr2 + n];
+                            if (p.out_rowmask) x *= om;
+                            if (p.accumulate) x += dst[e];
+                            dst[e] = x;
+                        }
                     }
                 }
             }
