@@ -655,29 +655,41 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
 
 // Sum of v[n] over the G lanes of a channel group, for all 16 n at once, by a halving butterfly:
 // afterwards lane l of the group (with l % (G/16) == 0) holds the total for n = l / (G/16).
+// x + (x of the partner lane) where the lower lane of a pair keeps x and the upper keeps y, for pairs 32 or 16 lanes
+// apart: the gfx950 lane-swap instructions exchange the two halves between two registers in one VALU operation
+// (no LDS crossbar, no selects), after which both lanes hold their two addends.
+template <int OFF>
+__device__ __forceinline__ float pair_swap_add(float x, float y) {
+    static_assert(OFF == 32 || OFF == 16, "lane-swap distances");
+    // Written as inline assembly with both registers read-write: this compiler's builtin for the instruction hands
+    // back the first result register for both outputs.  The leading s_nop covers the wait states the instruction
+    // needs after a VALU write of its operands (the compiler inserts the same before its own uses).
+    if constexpr (OFF == 32)
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    else
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+template <int OFF>
+__device__ __forceinline__ float pair_add(float lower_keeps, float upper_keeps) {
+    if constexpr (OFF == 32 || OFF == 16) {
+        return pair_swap_add<OFF>(lower_keeps, upper_keeps);
+    } else {
+        const bool up = (threadIdx.x & OFF) != 0;
+        return (up ? upper_keeps : lower_keeps) + __shfl_xor(up ? lower_keeps : upper_keeps, OFF);
+    }
+}
+
 template <int G>
 __device__ __forceinline__ float group_reduce16(const float (&v)[16]) {
-    const int lane = threadIdx.x;
     float w8[8], w4[4], w2[2], w1;
-    {
-        const bool up = (lane & (G / 2)) != 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w8[i] = (up ? v[i + 8] : v[i]) + __shfl_xor(up ? v[i] : v[i + 8], G / 2);
-    }
-    {
-        const bool up = (lane & (G / 4)) != 0;
+    for (int i = 0; i < 8; ++i) w8[i] = pair_add<G / 2>(v[i], v[i + 8]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w4[i] = (up ? w8[i + 4] : w8[i]) + __shfl_xor(up ? w8[i] : w8[i + 4], G / 4);
-    }
-    {
-        const bool up = (lane & (G / 8)) != 0;
+    for (int i = 0; i < 4; ++i) w4[i] = pair_add<G / 4>(w8[i], w8[i + 4]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) w2[i] = (up ? w4[i + 2] : w4[i]) + __shfl_xor(up ? w4[i] : w4[i + 2], G / 8);
-    }
-    {
-        const bool up = (lane & (G / 16)) != 0;
-        w1 = (up ? w2[1] : w2[0]) + __shfl_xor(up ? w2[0] : w2[1], G / 16);
-    }
+    for (int i = 0; i < 2; ++i) w2[i] = pair_add<G / 8>(w4[i], w4[i + 2]);
+    w1 = pair_add<G / 16>(w2[0], w2[1]);
 #pragma unroll
     for (int off = G / 32; off >= 1; off >>= 1) w1 += __shfl_xor(w1, off);
     return w1;
