@@ -28,6 +28,10 @@ __device__ __forceinline__ float silu_grad_(float x) {
 }
 __device__ __forceinline__ float softplus_(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
 
+template <class... P>
+inline bool aligned16(const P*... p) {
+    return ((reinterpret_cast<uintptr_t>(p) | ...) & 15) == 0;   // null pointers count as aligned
+}
 inline int grid_for(int64_t work, int per_block) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(work, per_block), kMaxGrid));
 }
@@ -442,6 +446,47 @@ __global__ __launch_bounds__(256) void binary_bwd_kernel(const float* __restrict
             da[i] = g[i] * b[i] * silu_grad_(a[i]);
             db[i] = g[i] * silu_(a[i]);
         }
+    }
+}
+
+// 16-byte forms of the three kernels above / below (n % 4 == 0, 16-byte aligned pointers; d % 4 == 0 for combine).
+__global__ __launch_bounds__(256) void binary_fwd_vec4_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                              int64_t n4, float c, int mode, float4* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i];
+        out[i] = mode == 0 ? make_float4(x.x * y.x * c, x.y * y.y * c, x.z * y.z * c, x.w * y.w * c)
+                           : make_float4(silu_(x.x) * y.x, silu_(x.y) * y.y, silu_(x.z) * y.z, silu_(x.w) * y.w);
+    }
+}
+__global__ __launch_bounds__(256) void binary_bwd_vec4_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                              const float4* __restrict__ g, int64_t n4, float c, int mode,
+                                                              float4* __restrict__ da, float4* __restrict__ db) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i], gg = g[i];
+        if (mode == 0) {
+            da[i] = make_float4(gg.x * y.x * c, gg.y * y.y * c, gg.z * y.z * c, gg.w * y.w * c);
+            db[i] = make_float4(gg.x * x.x * c, gg.y * x.y * c, gg.z * x.z * c, gg.w * x.w * c);
+        } else {
+            da[i] = make_float4(gg.x * y.x * silu_grad_(x.x), gg.y * y.y * silu_grad_(x.y), gg.z * y.z * silu_grad_(x.z),
+                                gg.w * y.w * silu_grad_(x.w));
+            db[i] = make_float4(gg.x * silu_(x.x), gg.y * silu_(x.y), gg.z * silu_(x.z), gg.w * silu_(x.w));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void combine_vec4_kernel(const float4* __restrict__ x0, const float4* __restrict__ x1,
+                                                           const float4* __restrict__ x2, const float4* __restrict__ x3,
+                                                           float c0, float c1, float c2, float c3,
+                                                           const float* __restrict__ rowmask, int64_t T, int d4,
+                                                           float4* __restrict__ out) {
+    const int64_t n = T * d4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float4 a = x0[i];
+        float4 v = make_float4(c0 * a.x, c0 * a.y, c0 * a.z, c0 * a.w);   // same operation order per element as the scalar form
+        if (x1) { const float4 t = x1[i]; v.x += c1 * t.x; v.y += c1 * t.y; v.z += c1 * t.z; v.w += c1 * t.w; }
+        if (x2) { const float4 t = x2[i]; v.x += c2 * t.x; v.y += c2 * t.y; v.z += c2 * t.z; v.w += c2 * t.w; }
+        if (x3) { const float4 t = x3[i]; v.x += c3 * t.x; v.y += c3 * t.y; v.z += c3 * t.z; v.w += c3 * t.w; }
+        if (rowmask) { const float m = rowmask[i / d4]; v.x *= m; v.y *= m; v.z *= m; v.w *= m; }
+        out[i] = v;
     }
 }
 
@@ -1197,7 +1242,12 @@ extern "C" int hmx_binary_fwd(const float* a, const float* b, int64_t n, float c
     HMX_ENTER();
     if (n == 0) return HMX_OK;
     if (!a || !b || !out || mode < 0 || mode > 1) return HMX_EINVAL;
-    hipLaunchKernelGGL(binary_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, c, mode, out);
+    if (n % 4 == 0 && aligned16(a, b, out))
+        hipLaunchKernelGGL(binary_fwd_vec4_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), n / 4, c, mode,
+                           reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(binary_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, c, mode, out);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -1207,8 +1257,14 @@ extern "C" int hmx_binary_bwd(const float* a, const float* b, const float* g, in
     HMX_ENTER();
     if (n == 0) return HMX_OK;
     if (!a || !b || !g || !da || !db || mode < 0 || mode > 1) return HMX_EINVAL;
-    hipLaunchKernelGGL(binary_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, g, n, c, mode,
-                       da, db);
+    if (n % 4 == 0 && aligned16(a, b, g, da, db))
+        hipLaunchKernelGGL(binary_bwd_vec4_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b),
+                           reinterpret_cast<const float4*>(g), n / 4, c, mode, reinterpret_cast<float4*>(da),
+                           reinterpret_cast<float4*>(db));
+    else
+        hipLaunchKernelGGL(binary_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, g, n, c, mode,
+                           da, db);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -1219,8 +1275,14 @@ extern "C" int hmx_combine_f32(const float* x0, const float* x1, const float* x2
     HMX_ENTER();
     if (T == 0) return HMX_OK;
     if (!x0 || !out || d <= 0) return HMX_EINVAL;
-    hipLaunchKernelGGL(combine_kernel, dim3(grid_for(T * d, 256)), dim3(256), 0, (hipStream_t)stream, x0, x1, x2, x3, c0, c1,
-                       c2, c3, rowmask, T, (int)d, out);
+    if (d % 4 == 0 && aligned16(x0, x1, x2, x3, out))
+        hipLaunchKernelGGL(combine_vec4_kernel, dim3(grid_for(T * d / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(x0), reinterpret_cast<const float4*>(x1),
+                           reinterpret_cast<const float4*>(x2), reinterpret_cast<const float4*>(x3), c0, c1, c2, c3, rowmask, T,
+                           (int)(d / 4), reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(combine_kernel, dim3(grid_for(T * d, 256)), dim3(256), 0, (hipStream_t)stream, x0, x1, x2, x3, c0,
+                           c1, c2, c3, rowmask, T, (int)d, out);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
