@@ -38,6 +38,9 @@ inline int grid_for(int64_t work, int per_block) {
 
 // ---------------------------------------------------------------------------- RMSNorm
 // y = x / sqrt(mean(x^2) + eps) * scale      (hydra3.py:221-229; eps inside the root)
+// Sixteen lanes per row; VEC = 4: lane l owns columns 4 l .. 4 l + 3 (+ 64 j), read and written 16 bytes at a time
+// (d % 4 == 0, 16-byte aligned rows); VEC = 1: columns l + 16 i.
+template <int VEC>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           int64_t T, int d, float eps, float* __restrict__ y,
                                                           float* __restrict__ rstd) {
@@ -46,21 +49,45 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
          row += (int64_t)gridDim.x * 16) {
         const bool ok = row < T;
         float ss = 0.f;
-        if (ok)
-            for (int c = l; c < d; c += 16) {
-                const float v = x[row * d + c];
-                ss += v * v;
+        float4 xv[4];
+        if (ok) {
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int c = 4 * l + 64 * jj;
+                    xv[jj] = c < d ? *reinterpret_cast<const float4*>(x + row * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ss += xv[jj].x * xv[jj].x + xv[jj].y * xv[jj].y + xv[jj].z * xv[jj].z + xv[jj].w * xv[jj].w;
+                }
+            } else {
+                for (int c = l; c < d; c += 16) {
+                    const float v = x[row * d + c];
+                    ss += v * v;
+                }
             }
+        }
         for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
         const float r = 1.f / sqrtf(ss / (float)d + eps);
         if (ok) {
-            for (int c = l; c < d; c += 16) y[row * d + c] = x[row * d + c] * r * scale[c];
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int c = 4 * l + 64 * jj;
+                    if (c < d) {
+                        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+                        *reinterpret_cast<float4*>(y + row * d + c) =
+                            make_float4(xv[jj].x * r * sc.x, xv[jj].y * r * sc.y, xv[jj].z * r * sc.z, xv[jj].w * r * sc.w);
+                    }
+                }
+            } else {
+                for (int c = l; c < d; c += 16) y[row * d + c] = x[row * d + c] * r * scale[c];
+            }
             if (l == 0 && rstd) rstd[row] = r;
         }
     }
 }
 
 // dx_j = r * (s_j dy_j - x_j r^2 mean_i(dy_i s_i x_i));  dscale_j = sum_t dy_j x_j r  (per-block partials)
+template <int VEC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                           const float* __restrict__ rstd, const float* __restrict__ dy,
                                                           int64_t T, int d, float* __restrict__ dx,
@@ -70,29 +97,66 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     float ds[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ds[i] = 0.f;
+    // column of this lane's i-th element
+    auto col = [&](int i) { return VEC == 4 ? 4 * l + (i & 3) + 64 * (i >> 2) : l + 16 * i; };
     for (int64_t row = (int64_t)blockIdx.x * 16 + slot; row < hmx_ceil_div(T, 16) * 16; row += (int64_t)gridDim.x * 16) {
         const bool ok = row < T;
         float dot = 0.f;
-        if (ok)
-            for (int c = l; c < d; c += 16) dot += dy[row * d + c] * scale[c] * x[row * d + c];
+        float xr[16], gr[16], sr[16];
+        if (ok) {
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int c = 4 * l + 64 * jj;
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), g = a, sc = a;
+                    if (c < d) {
+                        a = *reinterpret_cast<const float4*>(x + row * d + c);
+                        g = *reinterpret_cast<const float4*>(dy + row * d + c);
+                        sc = *reinterpret_cast<const float4*>(scale + c);
+                    }
+                    xr[4 * jj] = a.x; xr[4 * jj + 1] = a.y; xr[4 * jj + 2] = a.z; xr[4 * jj + 3] = a.w;
+                    gr[4 * jj] = g.x; gr[4 * jj + 1] = g.y; gr[4 * jj + 2] = g.z; gr[4 * jj + 3] = g.w;
+                    sr[4 * jj] = sc.x; sr[4 * jj + 1] = sc.y; sr[4 * jj + 2] = sc.z; sr[4 * jj + 3] = sc.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int c = l + 16 * i;
+                    xr[i] = c < d ? x[row * d + c] : 0.f;
+                    gr[i] = c < d ? dy[row * d + c] : 0.f;
+                    sr[i] = c < d ? scale[c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dot += gr[i] * sr[i] * xr[i];
+        }
         for (int off = 8; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
         if (ok) {
             const float r = rstd[row];
             const float coef = dot * r * r / (float)d;
+            float o[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int c = l + 16 * i;
-                if (c < d) {
-                    const float xv = x[row * d + c], g = dy[row * d + c];
-                    dx[row * d + c] = r * (scale[c] * g - xv * coef);
-                    ds[i] += g * xv * r;
+                o[i] = r * (sr[i] * gr[i] - xr[i] * coef);
+                ds[i] += gr[i] * xr[i] * r;
+            }
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int c = 4 * l + 64 * jj;
+                    if (c < d)
+                        *reinterpret_cast<float4*>(dx + row * d + c) = make_float4(o[4 * jj], o[4 * jj + 1], o[4 * jj + 2], o[4 * jj + 3]);
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (l + 16 * i < d) dx[row * d + l + 16 * i] = o[i];
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int c = l + 16 * i;
+        const int c = col(i);
         if (c < d) red[slot][c] = ds[i];
     }
     __syncthreads();
@@ -894,8 +958,12 @@ extern "C" int hmx_rmsnorm_fwd(const float* x, const float* scale, int64_t T, in
     HMX_ENTER();
     if (T == 0) return HMX_OK;
     if (!x || !scale || !y || d <= 0 || d > 256) return HMX_EINVAL;
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid_for(T, 16)), dim3(256), 0, (hipStream_t)stream, x, scale, T, (int)d,
-                       eps, y, rstd);
+    if (d % 4 == 0 && aligned16(x, scale, y))
+        hipLaunchKernelGGL(rmsnorm_fwd_kernel<4>, dim3(grid_for(T, 16)), dim3(256), 0, (hipStream_t)stream, x, scale, T,
+                           (int)d, eps, y, rstd);
+    else
+        hipLaunchKernelGGL(rmsnorm_fwd_kernel<1>, dim3(grid_for(T, 16)), dim3(256), 0, (hipStream_t)stream, x, scale, T,
+                           (int)d, eps, y, rstd);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -907,8 +975,12 @@ extern "C" int hmx_rmsnorm_bwd(const float* x, const float* scale, const float* 
     HMX_ENTER();
     if (T == 0) return HMX_OK;
     if (!x || !scale || !rstd || !dy || !dx || !dscale_part || d <= 0 || d > 256) return HMX_EINVAL;
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((int)hmx_rmsnorm_bwd_blocks(T)), dim3(256), 0, (hipStream_t)stream, x,
-                       scale, rstd, dy, T, (int)d, dx, dscale_part);
+    if (d % 4 == 0 && aligned16(x, scale, dy, dx))
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<4>, dim3((int)hmx_rmsnorm_bwd_blocks(T)), dim3(256), 0, (hipStream_t)stream, x,
+                           scale, rstd, dy, T, (int)d, dx, dscale_part);
+    else
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<1>, dim3((int)hmx_rmsnorm_bwd_blocks(T)), dim3(256), 0, (hipStream_t)stream, x,
+                           scale, rstd, dy, T, (int)d, dx, dscale_part);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
