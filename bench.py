@@ -4,9 +4,12 @@
 
 Workloads (synthetic data, shapes from BASELINE.json):
   retrieval  top-10 over a 4,000,001 x 64 item table for 1,000,000 user embeddings per step.
-             N > 1: the table is cut into S contiguous item-id ranges (--item-shards; default 2), the N / S
-             ranks holding a range split the queries, per-range lists are exchanged by RCCL all_gather and
-             merged (strong scaling: the work per step is fixed).  S = N is plain one-range-per-GPU sharding.
+             N > 1: the table is cut into S contiguous item-id ranges (--item-shards; default S = N, one range
+             per GPU, BASELINE.json configs[3]); every rank scores the queries against its range, the per-range
+             lists are exchanged by RCCL all_gather and merged (strong scaling: the work per step is fixed).
+             S < N (opt-in) lets the N / S ranks that hold a copy of a range split the queries.
+Started as `python bench.py --gpus N` without a launcher, the script starts the N ranks itself (torch.distributed.run
+on 127.0.0.1) before it touches the GPU; under torchrun it is one of the ranks.
   train      hydra3 train step (forward + backward + clip + AdamW), batch 1024 x seq 100, d 64.
 A "step" is one pass of the hot path over one batch; inputs are resident in HBM before timing.
 """
@@ -39,7 +42,7 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=100)
     ap.add_argument("--users", type=int, default=1_000_000)
     ap.add_argument("--item-shards", type=int, default=0,
-                    help="item-id ranges the table is cut into (0: 2 when N is even, else N); N / shards ranks "
+                    help="item-id ranges the table is cut into (0: N, one range per GPU); N / shards ranks "
                          "hold each range and split the queries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -114,7 +117,7 @@ def run_retrieval(args, world, rank):
     from generative_recommenders_amd.retrieval import ShardedRetriever, grid_layout, shard_bounds
     dev = torch.device("cuda", torch.cuda.current_device())
     n_rows, d, k = args.items + 1, args.dim, 10
-    item_shards = args.item_shards if args.item_shards > 0 else (2 if world % 2 == 0 else world)
+    item_shards = args.item_shards if args.item_shards > 0 else world      # configs[3]: one item range per GPU
     shard_index, S, qgroup, G = grid_layout(world, rank, item_shards)
     lo, hi = shard_bounds(n_rows, S, shard_index)
     # every rank draws the same full table from one seed and keeps its rows: identical to the unsharded run
@@ -154,7 +157,9 @@ def run_retrieval(args, world, rank):
         "data": "synthetic",
         "config": {"workload": "infer.py top-10 retrieval, 1M synthetic users x 4M items (configs[2]; sharded = configs[3])",
                    "queries": args.queries, "items": n_rows, "d": d, "k": k,
-                   "parallelism": (f"{S} item-range shards x {G} query groups, RCCL all_gather + merge"
+                   "parallelism": ((f"{S} item-range shards (one per GPU)" if G == 1 else
+                                    f"{S} item-range shards x {G} query groups") +
+                                   f", {os.environ.get('HMX_BENCH_BACKEND', 'nccl')} all_gather + merge"
                                    if world > 1 else "single GPU"),
                    "item_shards": S, "query_groups": G},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -169,8 +174,29 @@ def run_retrieval(args, world, rank):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as child processes and pass
+    rank 0's JSON line through.  Runs before this process has made any GPU call; nothing here initialises HIP
+    (torch.cuda.device_count() only counts devices)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < args.gpus and "HMX_BENCH_BACKEND" not in env:
+        # fewer GPUs than ranks (a one-GPU test box): rehearse the code path with the ranks sharing the GPUs over gloo
+        env["HMX_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     if os.environ.get("HMX_BENCH_WATCHDOG"):
         # diagnostics: dump every thread's Python stack and exit if the run is still going after that many seconds
         import faulthandler

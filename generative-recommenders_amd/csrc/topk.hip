@@ -53,6 +53,7 @@ struct CoarseParams {
     int64_t id_offset;
     const float* init_thr;    // (n_q_pad) starting threshold per query or null (-inf)   [bf16 pass]
     int* ring_error;          // set to 1 if a wave of the ring kernel gave up waiting (results then flagged uncertain)
+    int debug_skip_publish;   // test hook: stage whose publication workgroup 0 leaves out (-1: none)
     uint2* cand;              // [wave][g][lane][CAP] (score bits, local row)
     int* meta_cnt;            // [wave][g][lane]
     float* meta_thr;          // [wave][g][lane]
@@ -318,8 +319,13 @@ __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
 // published through an LDS generation counter and retired through an LDS completion counter, so the waves may
 // drift up to kStages - kLookahead stages apart (the filter's slow path makes their speeds uneven).
 // Progress: the wave that is furthest behind never waits -- every stage it needs was published by a wave that is
-// ahead of it, and the slot it must overwrite was retired by everyone -- so the ring cannot deadlock.  The waits
-// are bounded all the same; a wave that gives up sets ring_error and the launch's queries are re-run exactly.
+// ahead of it, and the slot it must overwrite was retired by everyone -- so the ring cannot deadlock.  Every wait
+// is bounded all the same, and the bound holds for the workgroup as a whole: a wave that gives up raises all
+// sixteen counters to kRingAbort, which ends every other wave's current or next wait at once and tells it (through
+// the value it has just read, no extra poll) to leave the stage loop.  An aborted workgroup consumes no slot it
+// did not see published, writes the lists it has (valid rows, incomplete), and sets ring_error, which marks every
+// query of the launch uncertain: they are re-run through the exact kernel.  Cost of a lost wake-up: one spin limit
+// (about 0.1 s) per workgroup, not one per remaining stage.
 // LDS rows are 128 B; the 16-byte chunk c of row r sits at chunk position c ^ (r & 7), which spreads the eight
 // rows read by neighbouring lanes over all banks without padding (the DMA needs a dense destination).
 constexpr int kRingWaves = 8;
@@ -327,7 +333,8 @@ constexpr int kStageTiles = 4;
 constexpr int kStages = 8;
 constexpr int kLookahead = 5;
 constexpr int kStageBytes = kStageTiles * 32 * 128;
-constexpr int kRingSpinLimit = 1 << 22;
+constexpr int kRingSpinLimit = 1 << 20;   // polls (s_sleep + LDS read, ~100 ns each) before a wait gives up
+constexpr int kRingAbort = 1 << 30;       // counter value that means "this workgroup has given up"
 
 template <int NB, int KP>
 __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(CoarseParams p) {
@@ -398,32 +405,40 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
     // would also wait for the wave's outstanding candidate stores to be acknowledged by memory, every stage.
     auto publish = [&](int s) {   // after the stage's DMA has landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every DMA of this wave has written LDS
-        if (lane == 0) __hip_atomic_store(&ready[s % kStages], s / kStages + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (s == p.debug_skip_publish && blockIdx.x == 0) return;   // test hook (wave-uniform)
+        // generations only grow, so a maximum is a store here -- except over kRingAbort, which must survive
+        if (lane == 0) __hip_atomic_fetch_max(&ready[s % kStages], s / kStages + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    auto wait_at_least = [&](int* flag, int target) {
-        int spins = 0;
+    // Returns true when the workgroup has given up (this wave's own wait ran out, or another wave's did).
+    auto wait_at_least = [&](int* flag, int target) -> bool {
+        int spins = 0, v;
         // wave-uniform poll: one lane's view of the counter decides for the wave (scalar compare and branch)
-        while (__builtin_amdgcn_readfirstlane(
-                   __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) {
+        while ((v = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > kRingSpinLimit) {
                 if (lane == 0) *p.ring_error = 1;
+                if (lane < 2 * kStages)
+                    __hip_atomic_store(lane < kStages ? &ready[lane] : &done[lane - kStages], kRingAbort, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                v = kRingAbort;
                 break;
             }
         }
         asm volatile("" ::: "memory");
+        return v >= kRingAbort;
     };
     const int n_full_stages = n_rows_here / (kStageTiles * 32);   // stages whose 128 rows all exist
     int pending = -1;
     // what a wave does on entering stage c: its fetching duty for stage c + kLookahead, then wait for stage c
-    auto enter_stage = [&](int c) {
+    auto enter_stage = [&](int c) -> bool {
         const int ahead = c + kLookahead;
         if (ahead < n_stages && (ahead % kRingWaves) == w) {
-            wait_at_least(&done[ahead % kStages], kRingWaves * (ahead / kStages));   // slot retired by all eight
+            if (wait_at_least(&done[ahead % kStages], kRingWaves * (ahead / kStages))) return true;   // slot retired by all eight
             fetch_stage(ahead, ahead >= n_full_stages);
             pending = ahead;
         }
-        wait_at_least(&ready[c % kStages], c / kStages + 1);
+        return wait_at_least(&ready[c % kStages], c / kStages + 1);
     };
     auto leave_stage = [&](int c) {
         if (pending >= 0) {
@@ -470,6 +485,7 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
     // filter then issues in the shadow of the matrix pipe instead of after it.  The idle set starts at -inf, so
     // the first step's filter passes nothing.
     short8 a0[KS];
+    bool aborted = false;
     if (n_full_stages > 0) {
         f32x16 accA[NB], accB[NB];
 #pragma unroll
@@ -498,9 +514,9 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
             }
         };
         static_assert(NB <= KS, "at most one filter group per MFMA quarter");
-        enter_stage(0);
-        read_tile(a0, smem, 0);
-        for (int c = 0; c < n_full_stages; ++c) {
+        aborted = enter_stage(0);
+        if (!aborted) read_tile(a0, smem, 0);
+        for (int c = 0; !aborted && c < n_full_stages; ++c) {
             const char* img = smem + (c % kStages) * kStageBytes;
             const int t = c * kStageTiles;
 #ifdef HMX_RING_PRIO
@@ -513,28 +529,37 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
             const char* next = img + 12288;               // no next full stage: re-read this tile (unused)
             if (c + 1 < n_full_stages) {
                 leave_stage(c);
-                enter_stage(c + 1);
+                if (enter_stage(c + 1)) {     // given up: the next stage is not there to be read
+                    aborted = true;
+                    break;
+                }
                 next = smem + ((c + 1) % kStages) * kStageBytes;
             }
             step(accB, accA, next, t + 2);
         }
-        leave_stage(n_full_stages - 1);
-        const int last_row0 = (int)row_begin + 32 * (n_full_stages * kStageTiles - 1) + 4 * h;
+        if (!aborted) {
+            leave_stage(n_full_stages - 1);
+            const int last_row0 = (int)row_begin + 32 * (n_full_stages * kStageTiles - 1) + 4 * h;
 #pragma unroll
-        for (int g = 0; g < NB; ++g)
-            tile_filter<KP, false>(accB[g], thr[g], cnt[g], wave_buf + g * 64 * CAP, last_row0, p, 0);
-    }
-    if (n_full_stages < n_stages) {       // the last, short stage: plain read-then-compute
-        const int c = n_full_stages;
-        enter_stage(c);
-        const char* img = smem + (c % kStages) * kStageBytes;
-        const int tiles_here = n_tiles - c * kStageTiles;
-        for (int tl = 0; tl < tiles_here; ++tl) {
-            read_tile(a0, img, tl);
-            compute_tile(a0, c * kStageTiles + tl, true);
+            for (int g = 0; g < NB; ++g)
+                tile_filter<KP, false>(accB[g], thr[g], cnt[g], wave_buf + g * 64 * CAP, last_row0, p, 0);
         }
-        leave_stage(c);
     }
+    if (!aborted && n_full_stages < n_stages) {       // the last, short stage: plain read-then-compute
+        const int c = n_full_stages;
+        aborted = enter_stage(c);
+        if (!aborted) {
+            const char* img = smem + (c % kStages) * kStageBytes;
+            const int tiles_here = n_tiles - c * kStageTiles;
+            for (int tl = 0; tl < tiles_here; ++tl) {
+                read_tile(a0, img, tl);
+                compute_tile(a0, c * kStageTiles + tl, true);
+            }
+            leave_stage(c);
+        }
+    }
+    // a wave that leaves early may still have a stage's DMA in flight: let it land before the wave ends
+    if (aborted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int g = 0; g < NB; ++g)
         finish_group<KP>(thr[g], cnt[g], wave_buf + (int64_t)g * 64 * CAP, p.meta_cnt + (wave * NB + g) * 64,
@@ -1077,6 +1102,8 @@ bool ring_shape(bool bf16, int NB, int KS, int64_t n_q) {
 }
 bool ring_pass(int NB, int64_t rows) { return NB == 4 || rows >= kRingMinRowsFewQueries; }
 
+int g_debug_skip_publish = -1;   // see hmx_debug_ring_skip_publish
+
 bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Plan& pl) {
     if (n_q <= 0 || n_rows <= 0 || d <= 0 || k <= 0 || k > 64 || n_rows >= ((int64_t)1 << 31)) return false;
     if (bf16 && d > 128) return false;
@@ -1289,6 +1316,11 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             p.id_offset = id_offset;
             p.init_thr = thr0;
             p.ring_error = (ring && ring_pass(plan.NB, rows)) ? ring_error : nullptr;
+            p.debug_skip_publish = -1;
+            if (p.ring_error != nullptr && rows == n_rows && g_debug_skip_publish >= 0) {   // one-shot test hook, full pass
+                p.debug_skip_publish = g_debug_skip_publish;
+                g_debug_skip_publish = -1;
+            }
             p.cand = cand;
             p.meta_cnt = meta_cnt;
             p.meta_thr = meta_thr;
@@ -1356,6 +1388,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
                 wp.q_bf16 = q_bf16;
                 wp.t_bf16 = table_bf16;
                 wp.dpad = pl.dpad;
+                wp.debug_skip_publish = -1;
                 void* span = hmx_profile_begin("topk_warm_bf16", s);
                 launch_warm(pl.NB, pl.KS, k <= 10 ? 5 : 8, wp, n_qtiles, n_sample, stride_tiles, init_thr, s);
                 hmx_profile_end(span, s);
@@ -1409,6 +1442,11 @@ extern "C" int hmx_score_topk_bf16(const float* queries, int64_t n_q, const floa
     HMX_ENTER();
     return run_topk(true, queries, n_q, table, table_bf16, max_row_norm, n_rows, d, k, exclude, n_excl, id_offset,
                     out_ids, out_scores, uncertain, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int hmx_debug_ring_skip_publish(int64_t stage) {
+    g_debug_skip_publish = stage >= 0 && stage < ((int64_t)1 << 30) ? (int)stage : -1;
+    return HMX_OK;
 }
 
 extern "C" int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_shards, int64_t n_q,

@@ -27,6 +27,7 @@ PROTOTYPES = {
     "hmx_score_topk_f32": (c_int, [P, I64, P, I64, I64, I64, P, I64, I64, P, P, P, c_size_t, P]),
     "hmx_score_topk_bf16": (c_int, [P, I64, P, P, P, I64, I64, I64, P, I64, I64, P, P, P, P, c_size_t, P]),
     "hmx_topk_merge": (c_int, [P, P, I64, I64, I64, P, P, P]),
+    "hmx_debug_ring_skip_publish": (c_int, [I64]),
     "hmx_attn1q_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, P, P]),
     "hmx_attn1q_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, P, P, P]),
     "hmx_pscan_fwd": (c_int, [P, P, I64, I64, I64, P, P]),

@@ -111,6 +111,13 @@ int hmx_score_topk_bf16(const float* queries, int64_t n_q, const float* table, c
                         int64_t n_excl, int64_t id_offset, int64_t* out_ids, float* out_scores,
                         int32_t* uncertain, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Test hook (no counterpart in the reference).  The shared-stream form of the bf16 coarse pass hands item rows from
+ * wave to wave through counters in LDS with bounded waits; a wait that runs out makes the whole workgroup stop
+ * early and flags every query of the launch `uncertain`.  This call arms a one-shot fault for the NEXT launch of
+ * that kernel in this process: workgroup 0 leaves out the publication of stage `stage` (>= 0; negative disarms), so
+ * its waves run into the bound.  Used by the GPU test of that path; not thread-safe, never needed in production. */
+int hmx_debug_ring_skip_publish(int64_t stage);
+
 /* Merge S per-shard top-K lists (cand_* laid out (S, n_q, K), as RCCL all_gather leaves
  * them) into the global top-K with the same order / tie-break.  Replaces nothing in the
  * reference (it is single-device); it is the exchange step of item-range sharding. */

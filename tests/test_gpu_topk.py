@@ -112,6 +112,31 @@ def test_many_query_launch_with_planted_rows_and_near_duplicates():
     assert st["uncertain"] >= 1                               # query 0 at least needs the exact pass
 
 
+def test_shared_stream_give_up_ends_early_and_is_rerun_exactly():
+    """A lost hand-off inside the shared-stream kernel (armed through the library's test hook: workgroup 0 never
+    publishes stage 7) must cost one bounded wait for that workgroup, not one per remaining stage: the launch comes
+    back quickly, every query of it is flagged, and the exact re-run still yields the oracle's ids and scores."""
+    import time
+    from generative_recommenders_amd import hmx
+    nq, rows = 16500, 70_003
+    q, t = _data(nq, rows, 64, 41)
+    qd, prep = q.to(DEV), ops.PreparedTable(t.to(DEV))
+    ids0, sc0, st0 = ops.score_topk(qd, prep, 10, return_stats=True)      # healthy run (also warms everything up)
+    assert st0["uncertain"] <= nq // 10
+    hmx.check(hmx.lib().hmx_debug_ring_skip_publish(7), "hmx_debug_ring_skip_publish")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ids, sc, st = ops.score_topk(qd, prep, 10, return_stats=True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert st["uncertain"] == nq                                           # the whole launch was flagged ...
+    assert elapsed < 2.0, elapsed                                          # ... after ONE bounded wait (~0.1 s)
+    assert torch.equal(ids, ids0) and torch.equal(sc, sc0)
+    _check(ids[:512], sc[:512], q[:512], t, 10)
+    ids2, sc2, st2 = ops.score_topk(qd, prep, 10, return_stats=True)      # the hook is one-shot
+    assert st2["uncertain"] == st0["uncertain"] and torch.equal(ids2, ids0)
+
+
 @pytest.mark.parametrize("nq,rows,k,with_excl", [(1024, 300_017, 50, True), (640, 262_144, 10, False),
                                                  (4100, 270_001, 10, False), (4096, 262_200, 50, True)])
 def test_few_query_shared_stream_shapes(nq, rows, k, with_excl):
