@@ -9,6 +9,7 @@ extern "C" const char* hmx_error_string(int code) {
         case HMX_EINVAL: return "invalid argument (shape, null pointer or unsupported size)";
         case HMX_EWORKSPACE: return "workspace too small";
         case HMX_ELAUNCH: return "HIP launch error";
+        case HMX_ELIMIT: return "input exceeds the fixed scratch size of this no-allocation entry point";
         default: return "unknown hmx error code";
     }
 }

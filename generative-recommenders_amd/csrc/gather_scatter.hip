@@ -4,6 +4,8 @@
 // A row is moved by a group of LPR = next_pow2(d/4) lanes, 16 B per lane, so a wave of
 // 64 lanes moves 64/LPR whole rows per instruction and every access is a full 16-B vector
 // inside one contiguous row segment.  d % 4 != 0 falls back to 4-B lanes.
+#include <mutex>
+
 #include "segment_sum.h"
 #include "profile.h"
 
@@ -126,6 +128,61 @@ extern "C" size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows
     return hmx_seg::workspace_bytes<hmx_seg::PlainRows>(n, n_rows, d);
 }
 
+static int scatter_add_impl(const float* grad_rows, const int64_t* ids, const int64_t* token_type, int64_t want_type,
+                            int64_t n, int64_t d, float* grad_table, int64_t n_rows, int64_t padding_idx,
+                            void* workspace, size_t workspace_bytes, hipStream_t s) {
+    const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_rows) | reinterpret_cast<uintptr_t>(grad_table)) % 16 == 0);
+    void* span = hmx_profile_begin("scatter_segment_sum", s);
+    const int rc = hmx_seg::sorted_segment_add(hmx_seg::PlainRows{grad_rows}, vec, ids, token_type, want_type, n, d,
+                                               grad_table, n_rows, padding_idx, workspace, workspace_bytes, s);
+    hmx_profile_end(span, s);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Scatter-add for callers that cannot allocate: the sort keys, sorted copies, run pieces and sort scratch live in a
+// fixed array inside the library's code object instead of a caller-provided workspace.  Each GPU has its own copy
+// of the array at its own address; `scratch` itself is only a host-side handle, so the device address is looked up
+// once per device with hipGetSymbolAddress and that pointer is what the kernels receive.
+constexpr size_t kScratchBytes = (size_t)16 << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mutex;
+
+static int scratch_of_current_device(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return HMX_ELAUNCH;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || ptr == nullptr) return HMX_ELAUNCH;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return HMX_OK;
+}
+
+extern "C" size_t hmx_scatter_add_rows_static_scratch_bytes(void) { return kScratchBytes; }
+
+extern "C" int hmx_scatter_add_rows_f32_static(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
+                                               int64_t want_type, int64_t n, int64_t d, float* grad_table,
+                                               int64_t n_rows, int64_t padding_idx, void* stream) {
+    HMX_ENTER();
+    if (n < 0 || d <= 0 || n_rows <= 0 || n >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 31)) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!grad_rows || !ids || !grad_table) return HMX_EINVAL;
+    if (hmx_seg::workspace_bytes<hmx_seg::PlainRows>(n, n_rows, d) > kScratchBytes) return HMX_ELIMIT;
+    void* ptr = nullptr;
+    const int rc = scratch_of_current_device(&ptr);
+    if (rc != HMX_OK) return rc;
+    // every word the kernels read from the scratch is written earlier in the same call (keys, values, their sorted
+    // copies, the pieces a join reads), so nothing has to be cleared between calls
+    return scatter_add_impl(grad_rows, ids, token_type, want_type, n, d, grad_table, n_rows, padding_idx, ptr,
+                            kScratchBytes, (hipStream_t)stream);
+}
+
 extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
                                         int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
                                         int64_t padding_idx, void* workspace, size_t workspace_bytes, void* stream) {
@@ -133,11 +190,6 @@ extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* i
     if (n < 0 || d <= 0 || n_rows <= 0 || n >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 31)) return HMX_EINVAL;
     if (n == 0) return HMX_OK;
     if (!grad_rows || !ids || !grad_table || !workspace) return HMX_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_rows) | reinterpret_cast<uintptr_t>(grad_table)) % 16 == 0);
-    void* span = hmx_profile_begin("scatter_segment_sum", s);
-    const int rc = hmx_seg::sorted_segment_add(hmx_seg::PlainRows{grad_rows}, vec, ids, token_type, want_type, n, d,
-                                               grad_table, n_rows, padding_idx, workspace, workspace_bytes, s);
-    hmx_profile_end(span, s);
-    return rc;
+    return scatter_add_impl(grad_rows, ids, token_type, want_type, n, d, grad_table, n_rows, padding_idx, workspace,
+                            workspace_bytes, (hipStream_t)stream);
 }

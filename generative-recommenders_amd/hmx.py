@@ -22,6 +22,8 @@ PROTOTYPES = {
     "hmx_gather_gelu_rows_f32": (c_int, [P, I64, I64, P, I64, P, P]),
     "hmx_scatter_add_rows_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "hmx_scatter_add_rows_f32": (c_int, [P, P, P, I64, I64, I64, P, I64, I64, P, c_size_t, P]),
+    "hmx_scatter_add_rows_static_scratch_bytes": (c_size_t, []),
+    "hmx_scatter_add_rows_f32_static": (c_int, [P, P, P, I64, I64, I64, P, I64, I64, P]),
     "hmx_table_prepare_bf16": (c_int, [P, I64, I64, P, P, P]),
     "hmx_score_topk_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
     "hmx_score_topk_f32": (c_int, [P, I64, P, I64, I64, I64, P, I64, I64, P, P, P, c_size_t, P]),

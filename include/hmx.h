@@ -31,6 +31,7 @@ extern "C" {
 #define HMX_EINVAL (-1)     /* bad shape / null pointer / unsupported size            */
 #define HMX_EWORKSPACE (-2) /* workspace too small                                    */
 #define HMX_ELAUNCH (-3)    /* HIP reported a launch error                            */
+#define HMX_ELIMIT (-4)     /* input larger than a fixed-size entry point supports    */
 
 int hmx_abi_version(void);
 const char* hmx_error_string(int code);
@@ -73,6 +74,19 @@ size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows, int64_t d
 int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
                              int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
                              int64_t padding_idx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same scatter-add for callers that cannot allocate device memory or hand over a workspace: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * The sort keys, their sorted copies, the run pieces and the sort's temporary storage live in a fixed array of
+ * hmx_scatter_add_rows_static_scratch_bytes() (16 MiB) inside the library, one copy per GPU, held until the process
+ * ends; the call allocates nothing.  Inputs whose hmx_scatter_add_rows_workspace_bytes(n, n_rows, d) exceeds that
+ * size (about 650,000 ids at d = 64) are refused with HMX_ELIMIT and nothing is enqueued.  Result: bit-identical to
+ * hmx_scatter_add_rows_f32.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
+ * (different streams or threads) race; calls on one stream, or on different GPUs, do not. */
+size_t hmx_scatter_add_rows_static_scratch_bytes(void);
+int hmx_scatter_add_rows_f32_static(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
+                                    int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
+                                    int64_t padding_idx, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Full-table inner-product scoring fused with top-K (no score matrix in HBM).
