@@ -148,7 +148,10 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                                 " (configs[4], per GPU)" if (L, d) == (512, 128) else ""),
                    "batch_per_gpu": B, "seq_len": L, "d": d, "users": args.users, "items": args.items,
                    "includes": "zero_grad, forward (encoder + miner top-50 + fused InfoNCE), backward, "
-                               "clip_grad_norm, AdamW; table gradients accumulated directly into .grad",
+                               "clip_grad_norm, AdamW; table gradients accumulated directly into .grad. Not evaluated: "
+                               "the neg_seqs gather + projection and the diversity term, which the reference computes "
+                               "and multiplies by its default weights 0.0 (hydra3.py:694-696,711,1146-1149): two row "
+                               "gathers per step here (seq, pos), three in the reference",
                    "parallelism": f"dp{world}" if world > 1 else "single GPU"},
         "fwd_bwd_ms": fwd_bwd_ms, "fwd_bwd_seqs_per_s": B * world / (fwd_bwd_ms * 1e-3), "loss": float(loss.item()),
         "roofline": {"bound": "hbm", "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

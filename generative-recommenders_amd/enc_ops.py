@@ -155,10 +155,13 @@ class _Linear(torch.autograd.Function):
         if need[0]:
             dx = _empty(T, K, like=x)
             _linear_raw(hmx.ptr(g), N, hmx.ptr(w), 1, ldw, None, T, K, N, hmx.ptr(dx), K, out_mask=in_mask)
+        want_db = ctx.has_bias and need[2]
         if need[1]:
             dw = torch.zeros_like(w) if ldw > K else torch.empty_like(w)
-            db = _empty(N, like=x) if (ctx.has_bias and need[2]) else None
+            db = _empty(N, like=x) if want_db else None
             _wgrad_raw(hmx.ptr(g), N, hmx.ptr(x), K, in_mask, T, N, K, hmx.ptr(dw), ldw, db, x.device)
+        elif want_db:            # frozen weight, trainable bias: the bias gradient is the column sum of dy
+            db = colsum(g)
         if need[5]:
             dr1 = g if ctx.c[0] == 1.0 else combine([g], [ctx.c[0]])
         if need[7]:

@@ -254,18 +254,25 @@ def _sample_inbatch_indices_no_self(M, rows, T, device):
 
 
 def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=None, hard_negatives=None, T=512,
-                                   hard_ratio=0.3, temperature=0.05, normalize=True, q_chunk=64, device=None):
+                                   hard_ratio=0.3, temperature=0.05, normalize=True, q_chunk=64, device=None,
+                                   predrawn=None):
     """hydra3.py:845-974 (InfoNCE over in-batch + hard negatives).  The negatives are drawn here exactly as the
     reference draws them (index tensors only); the loss itself -- hard-negative row gather, normalisation, the
     (M, 513) logits, log-softmax and the whole backward incl. the scatter into the item-table gradient -- is one
     fused HIP op, so no (M, 513, d) key tensor exists.  `q_chunk` only bounded the reference's memory use and has
-    no effect on the value; it is accepted and ignored."""
+    no effect on the value; it is accepted and ignored.
+    predrawn = (hard_ids (M, n) item-table rows or None, inb_idx (M, n') rows of the masked positives or None)
+    replaces the sampling: the loss is then a deterministic function of its inputs (used to compare a whole train
+    step with draws recorded from the reference, whose CPU generator a GPU cannot replay)."""
     device = log_feats.device
     mask = loss_mask.bool()
     q, k = log_feats[mask], pos_embs[mask]
     M = q.shape[0]
     if M == 0:
         return torch.tensor(0.0, device=device, requires_grad=True)
+    if predrawn is not None:
+        hard_ids, inb = predrawn
+        return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize).mean()
     num_hard = int(T * hard_ratio)
     num_inb = T - num_hard
     hard_ids = None
@@ -307,10 +314,10 @@ class EnhancedTrainingLoss(nn.Module):
         self.q_chunk = getattr(args, 'loss_q_chunk', 256)          # hydra3.py:1132
         self.adaptive_hard_sampler = AdaptiveHardNegativeSampler()
 
-    def forward(self, user_embs, pos_embs, neg_embs, hard_negatives, loss_mask, item_table):
+    def forward(self, user_embs, pos_embs, neg_embs, hard_negatives, loss_mask, item_table, predrawn=None):
         total = self.contrastive_loss_weight * compute_mixed_contrastive_loss(
             user_embs, pos_embs, loss_mask, item_table, hard_negatives, hard_ratio=0.3, T=512, temperature=0.05,
-            q_chunk=self.q_chunk)
+            q_chunk=self.q_chunk, predrawn=predrawn)
         self.adaptive_hard_sampler.update_step()
         if neg_embs is not None and self.ranking_loss_weight != 0.0:
             u, p, n, lm = user_embs[:, -1], pos_embs[:, -1], neg_embs[:, -1], loss_mask[:, -1]
@@ -410,8 +417,12 @@ class Hydra(nn.Module):
         return self._prepared
 
     def forward(self, user_item, pos_seqs, neg_seqs, mask, next_mask, next_action_type, seq_feature, pos_feature,
-                neg_feature, timestamp, action_type, dwell_bins):
-        """hydra3.py:683-720."""
+                neg_feature, timestamp, action_type, dwell_bins, predrawn=None):
+        """hydra3.py:683-720.  The negative-item branch (gather + projection of neg_seqs, hydra3.py:694-696, 711) and
+        the diversity term (:1146-1149) enter the reference's loss with weight 0.0 by default; they are evaluated
+        here only when their weights are non-zero (the loss value and every gradient are the same either way).
+        predrawn: see compute_mixed_contrastive_loss.  The mined hard-negative ids of the call are kept in
+        self.last_mined_ids."""
         log_feats = self.log2feats(user_item, seq_feature, mask, timestamp, action_type, dwell_bins)
         se = self.shared_embeddings
         item_table = se.item_emb.weight
@@ -423,9 +434,10 @@ class Hydra(nn.Module):
         miner = HardNegativeMiner(self, item_table, top_k=50, prepared=self.prepared_item_table())
         hard = miner.mine_hard_negatives_similarity(log_feats[:, -1, :], positive_items=pos_seqs,
                                                     exclude_items=user_item)
+        self.last_mined_ids = hard
         hard = hard.unsqueeze(1).expand(-1, log_feats.shape[1], -1)
         return self.enchanced_loss(user_embs=log_feats, pos_embs=pos_embs, neg_embs=neg_embs, hard_negatives=hard,
-                                   loss_mask=(next_mask == 1), item_table=item_table)
+                                   loss_mask=(next_mask == 1), item_table=item_table, predrawn=predrawn)
 
 
 IDS_ONLY_FEAT_TYPES = {k: [] for k in ('user_sparse', 'item_sparse', 'user_array', 'item_array',
@@ -453,25 +465,3 @@ def build_model(n_users, n_items, d=64, L=100, heads=2, blocks=2, dropout=0.2, d
     for t in (se.pos_emb, se.item_emb, se.user_emb, se.action_emb):
         t.weight.data[0].zero_()
     return model.to(device)
-
-
-def smoke(dev):
-    """Tiny forward + backward of the whole model on `dev`, checked against the CPU oracle."""
-    from oracle import hydra_oracle as O
-    from . import synth
-    U, I, d, L, B = 50, 300, 64, 12, 4
-    ref = O.build_model(U, I, d=d, L=L, dropout=0.0, seed=3)
-    model = Hydra(U, I, {}, IDS_ONLY_FEAT_TYPES, make_args(d, L, dropout=0.0, device=str(dev)),
-                  SharedEmbeddingModule(U, I, {}, IDS_ONLY_FEAT_TYPES, make_args(d, L, dropout=0.0, device=str(dev))))
-    model.load_state_dict(ref.state_dict(), strict=True)
-    model.to(dev)
-    bt = synth.train_batch(B, L, U, I, "cpu", seed=5, pad_frac=0.3)
-    feat = [[] for _ in range(B)]
-    want = ref.log2feats(bt["seq"], feat, bt["tok"], bt["ts"], bt["act"], bt["dwell"])
-    g = {k: v.to(dev) for k, v in bt.items()}
-    got = model.log2feats(g["seq"], feat, g["tok"], g["ts"], g["act"], g["dwell"])
-    err = (got.detach().cpu() - want.detach()).abs().max().item()
-    scale = want.detach().abs().max().item()
-    assert err <= 0.03 * scale + 1e-3, f"log2feats mismatch: {err} vs scale {scale}"
-    got.square().mean().backward()
-    assert model.shared_embeddings.item_emb.weight.grad is not None

@@ -135,6 +135,21 @@ def g4_mamba(store):
         module_case(store, f"G4_mamba_hd{hd}", m, [torch.randn(B, L, hd)])
 
 
+def g12_d128(store):
+    """The long-history configuration's widths (d = 128: head_dim 64, inner width 256): one MambaBlock and one
+    regular HydraBlock."""
+    torch.manual_seed(1264)
+    m = ref.MambaBlock(64, 16, 256, 16)
+    xavier_(m)
+    module_case(store, "G12_mamba_hd64", m, [torch.randn(2, 19, 64)])
+    torch.manual_seed(1228)
+    a = make_args(128, 11)
+    blk = ref.HydraBlock(128, 16, 512, 16, a)
+    xavier_(blk)
+    pm = pad_mask(2, 11, (0, 4))
+    module_case(store, "G12_block_regular_d128", blk, [torch.randn(2, 11, 128) * pm, pm])
+
+
 def pad_mask(B, L, pads):
     m = torch.ones(B, L, 1)
     for b, p in enumerate(pads):
@@ -266,14 +281,35 @@ def g10_train(store):
         m.train()
         bt = synth_batch(B, L, U, I, pads=(0, 2, L - 3, 5, 0, 0, 1, 7)[:B], seed=1010 + B)
         feat = [[] for _ in range(B)]
+        # The reference's own random draws and mined ids are recorded on the way (data, in call order): torch.randint
+        # is wrapped for the duration of the forward pass, which does not touch the generator's stream.
+        draws, mined = [], []
+        real_randint, real_mine = torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity
+
+        def rec_randint(*a_, **k_):
+            out = real_randint(*a_, **k_)
+            draws.append(out.clone())
+            return out
+
+        def rec_mine(self, *a_, **k_):
+            out = real_mine(self, *a_, **k_)
+            mined.append(out.clone())
+            return out
+
         torch.manual_seed(4242)
-        with quiet():
-            loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat,
-                     bt["ts"], bt["act"], bt["dwell"])
+        torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity = rec_randint, rec_mine
+        try:
+            with quiet():
+                loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat,
+                         bt["ts"], bt["act"], bt["dwell"])
+        finally:
+            torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity = real_randint, real_mine
         loss.backward()
         prefix = f"G10_train_{name}"
         put_params(store, prefix, m)
-        put(store, prefix, loss=loss, rng_seed=4242, U=U, I=I, d=d, L=L, **bt)
+        put(store, prefix, loss=loss, rng_seed=4242, U=U, I=I, d=d, L=L, mined_ids=mined[0], n_draws=len(draws), **bt)
+        for i, dr in enumerate(draws):
+            store[f"{prefix}/draw{i}"] = dr.numpy()
         for k, p in m.named_parameters():
             if p.grad is None:
                 continue
@@ -313,7 +349,7 @@ def main():
     only = set(sys.argv[1:])
     groups = {"g1_pscan": g1_pscan, "g2_selective_scan": g2_selective_scan, "g3_rmsnorm": g3_rmsnorm,
               "g4_mamba": g4_mamba, "g5_mhm": g5_mhm, "g6_blocks": g6_blocks, "g7_multiscale": g7_multiscale,
-              "g9_topk": g9_topk, "g10_train": g10_train, "g11_item_embs": g11_item_embs}
+              "g9_topk": g9_topk, "g10_train": g10_train, "g11_item_embs": g11_item_embs, "g12_d128": g12_d128}
     for fname, fn in groups.items():
         if only and fname not in only:
             continue

@@ -205,6 +205,21 @@ def test_full_size_properties():
     assert st_m["uncertain"] <= 8
 
 
+def test_full_size_table_against_c_oracle():
+    """16 queries x 4,000,001 rows: ids and scores of both HIP paths against the C oracle's exhaustive scan (the
+    same fma-chain score definition), bit for bit -- the full-size check that does not compare HIP with HIP."""
+    rows, d = 4_000_001, 64
+    g = torch.Generator().manual_seed(77)
+    t = torch.randn(rows, d, generator=g)
+    t[0] = 0
+    q = torch.randn(16, d, generator=g)
+    want_ids, want_sc = C.score_topk(q.numpy(), t.numpy(), 10)
+    td = t.to(DEV)
+    for ids, sc in (ops.score_topk(q.to(DEV), ops.PreparedTable(td), 10), ops.score_topk_exact(q.to(DEV), td, 10)):
+        assert np.array_equal(ids.cpu().numpy(), want_ids)
+        assert np.array_equal(sc.cpu().numpy(), want_sc)
+
+
 def test_launch_shape_toggles_do_not_change_results(tmp_path):
     """The shared-stream kernel and the sampled start thresholds are speed features: with either switched off
     (fresh processes, the switches are read once) ids and scores must be bit-identical to the default path."""

@@ -160,6 +160,34 @@ def test_train_step_loss_and_grads(name):
         assert float(g[0].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("name", ["small", "chunky"])
+def test_recorded_draws_reproduce_the_reference_loss(name):
+    """The fixture also holds what the reference drew (its torch.randint outputs and mined ids).  Assembled into
+    index tensors (tests/_golden.py) and fed to the index form of the loss, they must give the reference's loss:
+    this pins the assembly that the GPU train-step test relies on."""
+    s, p = G.load("g10_train"), f"G10_train_{name}"
+    m = _model_from(s, p, dropout=0.0).train()
+    b = {k: G.t(s, f"{p}/{k}") for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    with torch.no_grad():
+        lf = m.log2feats(b["seq"], feat, b["tok"], b["ts"], b["act"], b["dwell"])
+        table = m.shared_embeddings.item_emb.weight
+        pos = m.hydra_projection(m.shared_embeddings.get_complete_embeddings(b["pos"], feat, b["tok"], False, 'early', 'hydra'))
+        mined = O.HardNegativeMiner(m, table, 50).mine_hard_negatives_similarity(lf[:, -1], b["pos"], b["seq"])
+        assert torch.equal(mined, G.t(s, p + "/mined_ids"))
+        mask = b["next_tok"] == 1
+        hard, inb = G.assemble_train_draws(s, p, mask)
+        loss = O.nce_rows(lf[mask], pos[mask], table, hard, inb).mean()
+    G.assert_close(loss, G.t(s, p + "/loss"), 2e-5, 2e-5, "loss from recorded draws")
+
+
+def test_d128_widths_match_reference():
+    """MambaBlock at head_dim 64 (inner width 256) and a regular HydraBlock at d = 128: the long-history widths."""
+    s = G.load("g12_d128")
+    _run_module_case(s, "G12_mamba_hd64", O.MambaBlock(64, 16, 256, 16), 1)
+    _run_module_case(s, "G12_block_regular_d128", O.HydraBlock(128, 16, 512, 16, O.make_args(128, 11)), 2)
+
+
 def test_candidate_embedding_generation_matches_reference():
     """embedding.py:654-735 (ids-only): the oracle's late-fusion rows against what the reference produced."""
     s = G.load("g11_item_embs")
