@@ -10,6 +10,11 @@
 
 #include "hmx_common.h"
 
+// The library is built with -ffp-contract=off because the gather / scatter / scoring kernels promise bit-exact sums in
+// a stated order.  The encoder promises a tolerance instead (its projections run on bf16 MFMA), and its scan kernels
+// are bound by vector-instruction issue: here a multiply followed by an add may fuse into one fma.
+#pragma clang fp contract(fast)
+
 namespace {
 
 using short8 = __attribute__((ext_vector_type(8))) short;
@@ -20,13 +25,18 @@ constexpr int kR = 16;   // dt rank          (dt_rank, hydra3.py:591)
 constexpr int kP = kR + 2 * kN;
 constexpr int kMaxGrid = 4096;
 
-__device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + __expf(-x)); }
+// 1 / (1 + e^-x) with the hardware reciprocal (1 ulp) instead of an IEEE division (ten instructions)
+__device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float silu_(float x) { return x * sigmoid_(x); }
 __device__ __forceinline__ float silu_grad_(float x) {
     const float s = sigmoid_(x);
     return s * (1.f + x * (1.f - s));
 }
-__device__ __forceinline__ float softplus_(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+// log(1 + e^x) = max(x, 0) + log(1 + e^-|x|): the argument of the logarithm stays in (1, 2], where the hardware
+// logarithm is accurate to an ulp of the result; for x > 20 the sum is x in fp32 (the reference's threshold form).
+__device__ __forceinline__ float softplus_(float x) {
+    return x > 20.f ? x : fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x)));
+}
 
 template <class... P>
 inline bool aligned16(const P*... p) {
@@ -699,11 +709,18 @@ struct ScanParams {
     const float* D;      // (C)
     int B, L, C, ED, H;
     float* yg;           // (T, C)
-    float* hs;           // (T, 4, C, 4) or null: states kept for the backward pass, state n of channel c at
-                         // [t][n / 4][c][n % 4], so that one 16-byte store per lane writes whole cache lines per wave
+    float* hs;           // (B, n_ck, 4, C, 4) or null: state checkpoints for the backward pass, one every kCk steps:
+                         // checkpoint j of a sequence is the state after step kCk * (j + 1) - 1 (the state that enters
+                         // sub-chunk j + 1), n_ck = (L - 1) / kCk; state n of channel c at [n / 4][c][n % 4], so that
+                         // one 16-byte store per lane writes whole cache lines per wave.  The backward pass recomputes
+                         // the states in between (kCk steps at a time, parked in LDS) instead of reading them back:
+                         // 1 / kCk of the state traffic in both directions.
 };
 
-constexpr int kScanChunk = 64;  // time steps of dbc staged per LDS fill
+constexpr int kScanChunk = 64;  // time steps of dbc staged per LDS fill (forward)
+constexpr int kCk = 4;          // steps between state checkpoints
+constexpr int kScanChunkBwd = 32;  // backward: dbc rows per LDS fill (a multiple of kCk; leaves room for the state history)
+__host__ __device__ inline int scan_n_ck(int L) { return L > 1 ? (L - 1) / kCk : 0; }
 
 __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -751,8 +768,9 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
                 h[n] = a * h[n] + (delta * r[kR + n]) * x;
                 y += h[n] * r[kR + kN + n];
             }
-            if (p.hs) {
-                float4* dst = reinterpret_cast<float4*>(p.hs) + row * 4 * p.C + c;
+            const int tl = tc0 + s;   // position in the sequence
+            if (p.hs && ((tl + 1) % kCk) == 0 && tl + 1 < p.L) {
+                float4* dst = reinterpret_cast<float4*>(p.hs) + (seq * scan_n_ck(p.L) + (tl + 1) / kCk - 1) * 4 * p.C + c;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     dst[(int64_t)q * p.C] = make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
@@ -815,9 +833,11 @@ struct ScanBwdParams {
 };
 
 template <int G>
-__global__ __launch_bounds__(256) void scan_bwd_kernel(ScanBwdParams q) {
+__global__ __launch_bounds__(256, 2) void scan_bwd_kernel(ScanBwdParams q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* rows = reinterpret_cast<float*>(smem);
+    // [kCk][4][256] float4: the states of the current sub-chunk, recomputed from its checkpoint; then the dbc rows
+    float4* hist = reinterpret_cast<float4*>(smem);
+    float* rows = reinterpret_cast<float*>(smem + (size_t)kCk * 4 * 256 * sizeof(float4));
     const ScanParams& p = q.f;
     const int c = blockIdx.y * 256 + threadIdx.x;   // C is a multiple of G (host-checked), so whole groups are live
     const bool live = c < p.C;
@@ -826,6 +846,7 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(ScanBwdParams q) {
     const int gih = ce / G, lig = ce % G;
     const int64_t seq = blockIdx.x;
     const int HP = p.H * kP;
+    const int n_ck = scan_n_ck(p.L);
     float A[kN], Wd[kR], carry[kN], dA[kN], dWd[kR];
 #pragma unroll
     for (int n = 0; n < kN; ++n) {
@@ -837,85 +858,129 @@ __global__ __launch_bounds__(256) void scan_bwd_kernel(ScanBwdParams q) {
     }
     const float bd = p.bdt[cc], Dv = p.D[cc];
     float dbd = 0.f, dD = 0.f;
-    const int n_chunks = (p.L + kScanChunk - 1) / kScanChunk;
+    const int n_chunks = (p.L + kScanChunkBwd - 1) / kScanChunkBwd;
+    const float4* ckp = reinterpret_cast<const float4*>(p.hs);
+    // Operands of one sub-chunk (kCk steps): x, z, dy of its steps and the checkpoint that enters it.  They are
+    // requested one sub-chunk ahead (unconditionally, clamped at the sequence start) so that their latency hides
+    // behind the recompute + backward arithmetic of the current sub-chunk.
+    float nx[kCk], nz[kCk], ngy[kCk];
+    float4 nh[4];
+    auto request = [&](int t0) {     // sub-chunk starting at position t0 (a multiple of kCk), t0 >= 0
+#pragma unroll
+        for (int u = 0; u < kCk; ++u) {
+            const int64_t rr = seq * p.L + min(t0 + u, p.L - 1);
+            nx[u] = p.xc[rr * p.C + c];
+            nz[u] = p.xz ? p.xz[rr * p.C + c] : 0.f;
+            ngy[u] = q.dyg[rr * p.C + c];
+        }
+        const int j = t0 / kCk - 1;   // checkpoint entering the sub-chunk (none for the first: zeros)
+        const float4* src = ckp + (seq * n_ck + max(j, 0)) * 4 * p.C + c;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) nh[k4] = (n_ck > 0) ? src[(int64_t)k4 * p.C] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const int t_last = ((p.L - 1) / kCk) * kCk;     // start of the last sub-chunk
+    if (live) request(t_last);
     for (int ch = n_chunks - 1; ch >= 0; --ch) {
-        const int tc0 = ch * kScanChunk;
-        const int steps = min(kScanChunk, p.L - tc0);
+        const int tc0 = ch * kScanChunkBwd;
+        const int steps = min(kScanChunkBwd, p.L - tc0);
         __syncthreads();
         for (int idx = threadIdx.x; idx < steps * HP; idx += 256) rows[idx] = p.dbc[(seq * p.L + tc0) * HP + idx];
         __syncthreads();
         if (!live) continue;
-        // The step's global operands (saved state, x, z, dy) are requested one step ahead: the loads of step s - 1
-        // are in flight while step s computes.  The last step of a chunk re-requests its own row (unconditional
-        // loads keep the compiler's wait counts from serialising the pipeline).
-        float4 nh[4];
-        float nx, nz, ngy;
-        auto request = [&](int s_req) {
-            const int64_t rr = seq * p.L + tc0 + s_req;
-            const float4* src = reinterpret_cast<const float4*>(p.hs) + rr * 4 * p.C + c;
+        for (int s0 = ((steps - 1) / kCk) * kCk; s0 >= 0; s0 -= kCk) {   // sub-chunks of this fill, last first
+            const int t0 = tc0 + s0;
+            const int ns = min(kCk, p.L - t0);
+            float x[kCk], z[kCk], gy[kCk], h[kN];
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) nh[k4] = src[(int64_t)k4 * p.C];
-            nx = p.xc[rr * p.C + c];
-            nz = p.xz ? p.xz[rr * p.C + c] : 0.f;
-            ngy = q.dyg[rr * p.C + c];
-        };
-        request(steps - 1);
-        for (int s = steps - 1; s >= 0; --s) {
-            const int64_t row = seq * p.L + tc0 + s;
-            const float x = nx, z = nz, gy = ngy;
-            const float* r = rows + s * HP + hh * kP;
-            float hcur[kN];
+            for (int u = 0; u < kCk; ++u) {
+                x[u] = nx[u];
+                z[u] = nz[u];
+                gy[u] = ngy[u];
+            }
+            const bool first = t0 == 0;
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
-                hcur[4 * k4] = nh[k4].x; hcur[4 * k4 + 1] = nh[k4].y; hcur[4 * k4 + 2] = nh[k4].z; hcur[4 * k4 + 3] = nh[k4].w;
+                h[4 * k4] = first ? 0.f : nh[k4].x; h[4 * k4 + 1] = first ? 0.f : nh[k4].y;
+                h[4 * k4 + 2] = first ? 0.f : nh[k4].z; h[4 * k4 + 3] = first ? 0.f : nh[k4].w;
             }
-            request(max(s - 1, 0));
-            float dpre = 0.f;
+            request(max(t0 - kCk, 0));
+            // forward recompute of the sub-chunk's states (same operations, same order as scan_fwd_kernel)
+            float dpre_s[kCk];
 #pragma unroll
-            for (int k = 0; k < kR; ++k) dpre += Wd[k] * r[k];
-            dpre += bd;
-            const float delta = softplus_(dpre);
-            float y = 0.f;
+            for (int u = 0; u < kCk; ++u) {
+                if (u < ns) {
+                    const float* r = rows + (s0 + u) * HP + hh * kP;
+                    float dpre = 0.f;
 #pragma unroll
-            for (int n = 0; n < kN; ++n) y += hcur[n] * r[kR + kN + n];
-            const float ypre = y + Dv * x;
-            const float dy = p.xz ? gy * silu_(z) : gy;
-            if (p.xz) q.dxz[row * p.C + c] = gy * ypre * silu_grad_(z);
-            dD += dy * x;
-            float dx = Dv * dy, ddelta = 0.f;
-            float vB[kN], vC[kN];
+                    for (int k = 0; k < kR; ++k) dpre += Wd[k] * r[k];
+                    const float delta = softplus_(dpre + bd);
+                    dpre_s[u] = dpre + bd;
 #pragma unroll
-            for (int n = 0; n < kN; ++n) {
-                const float a = __expf(delta * A[n]);
-                const float Bn = r[kR + n];
-                const float g = r[kR + kN + n] * dy + carry[n];   // dL/dh_t[n]
-                carry[n] = a * g;
-                const float bterm = delta * Bn * x;
-                const float hprev_a = hcur[n] - bterm;            // a_t * h_{t-1}
-                ddelta += g * (A[n] * hprev_a + Bn * x);
-                dA[n] += g * delta * hprev_a;
-                dx += g * delta * Bn;
-                vB[n] = g * delta * x;
-                vC[n] = dy * hcur[n];
+                    for (int n = 0; n < kN; ++n) {
+                        const float a = __expf(delta * A[n]);
+                        h[n] = a * h[n] + (delta * r[kR + n]) * x[u];
+                    }
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4)
+                        hist[(u * 4 + k4) * 256 + threadIdx.x] = make_float4(h[4 * k4], h[4 * k4 + 1], h[4 * k4 + 2], h[4 * k4 + 3]);
+                }
             }
-            q.dxc[row * p.C + c] = dx;
-            const float dd = ddelta * (dpre > 20.f ? 1.f : sigmoid_(dpre));
-            dbd += dd;
-            float vR[kR];
+            // backward over the sub-chunk (a thread reads back only what it wrote itself: no barrier needed)
 #pragma unroll
-            for (int k = 0; k < kR; ++k) {
-                dWd[k] += dd * r[k];
-                vR[k] = dd * Wd[k];
-            }
-            const float sR = group_reduce16<G>(vR);
-            const float sB = group_reduce16<G>(vB);
-            const float sC = group_reduce16<G>(vC);
-            if ((lig & (G / 16 - 1)) == 0) {
-                const int n = lig / (G / 16);
-                float* o = q.ddbc_part + ((row * p.H + hh) * q.GPH + gih) * kP;
-                o[n] = sR;
-                o[kR + n] = sB;
-                o[kR + kN + n] = sC;
+            for (int u = kCk - 1; u >= 0; --u) {
+                if (u >= ns) continue;
+                const int64_t row = seq * p.L + t0 + u;
+                const float* r = rows + (s0 + u) * HP + hh * kP;
+                float hcur[kN];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 v = hist[(u * 4 + k4) * 256 + threadIdx.x];
+                    hcur[4 * k4] = v.x; hcur[4 * k4 + 1] = v.y; hcur[4 * k4 + 2] = v.z; hcur[4 * k4 + 3] = v.w;
+                }
+                const float dpre = dpre_s[u];
+                const float delta = softplus_(dpre);
+                float y = 0.f;
+#pragma unroll
+                for (int n = 0; n < kN; ++n) y += hcur[n] * r[kR + kN + n];
+                const float ypre = y + Dv * x[u];
+                const float dy = p.xz ? gy[u] * silu_(z[u]) : gy[u];
+                if (p.xz) q.dxz[row * p.C + c] = gy[u] * ypre * silu_grad_(z[u]);
+                dD += dy * x[u];
+                float dx = Dv * dy, ddelta = 0.f;
+                float vB[kN], vC[kN];
+#pragma unroll
+                for (int n = 0; n < kN; ++n) {
+                    const float a = __expf(delta * A[n]);
+                    const float Bn = r[kR + n];
+                    const float g = r[kR + kN + n] * dy + carry[n];   // dL/dh_t[n]
+                    carry[n] = a * g;
+                    const float bterm = delta * Bn * x[u];
+                    const float hprev_a = hcur[n] - bterm;            // a_t * h_{t-1}
+                    ddelta += g * (A[n] * hprev_a + Bn * x[u]);
+                    dA[n] += g * delta * hprev_a;
+                    dx += g * delta * Bn;
+                    vB[n] = g * delta * x[u];
+                    vC[n] = dy * hcur[n];
+                }
+                q.dxc[row * p.C + c] = dx;
+                const float dd = ddelta * (dpre > 20.f ? 1.f : sigmoid_(dpre));
+                dbd += dd;
+                float vR[kR];
+#pragma unroll
+                for (int k = 0; k < kR; ++k) {
+                    dWd[k] += dd * r[k];
+                    vR[k] = dd * Wd[k];
+                }
+                const float sR = group_reduce16<G>(vR);
+                const float sB = group_reduce16<G>(vB);
+                const float sC = group_reduce16<G>(vC);
+                if ((lig & (G / 16 - 1)) == 0) {
+                    const int n = lig / (G / 16);
+                    float* o = q.ddbc_part + ((row * p.H + hh) * q.GPH + gih) * kP;
+                    o[n] = sR;
+                    o[kR + n] = sB;
+                    o[kR + kN + n] = sC;
+                }
             }
         }
     }
@@ -1402,6 +1467,11 @@ static bool scan_shape_ok(int64_t C, int64_t ED, int64_t H) {
     return ED >= 32 && (ED & (ED - 1)) == 0 && C == ED * H && H * kP * kScanChunk * 4 <= 64 * 1024;
 }
 
+extern "C" int64_t hmx_scan_state_floats(int64_t B, int64_t L, int64_t C) {
+    if (B <= 0 || L <= 0 || C <= 0) return 0;
+    return B * (int64_t)scan_n_ck((int)L) * C * kN;
+}
+
 extern "C" int hmx_scan_fwd(const float* xc, const float* xz, const float* dbc, const float* Wdt, const float* bdt,
                             const float* A_log, const float* D, int64_t B, int64_t L, int64_t C, int64_t ED, int64_t H,
                             float* yg, float* hs, void* stream) {
@@ -1423,8 +1493,8 @@ extern "C" int hmx_scan_bwd(const float* xc, const float* xz, const float* dbc, 
                             float* par_part, void* stream) {
     HMX_ENTER();
     if (B == 0) return HMX_OK;
-    if (!xc || !dbc || !Wdt || !bdt || !A_log || !D || !hs || !dyg || !dxc || (xz && !dxz) || !ddbc_part || !par_part ||
-        L <= 0 || !scan_shape_ok(C, ED, H))
+    if (!xc || !dbc || !Wdt || !bdt || !A_log || !D || (!hs && scan_n_ck((int)L) > 0) || !dyg || !dxc || (xz && !dxz) ||
+        !ddbc_part || !par_part || L <= 0 || !scan_shape_ok(C, ED, H))
         return HMX_EINVAL;
     ScanBwdParams q{};
     q.f = ScanParams{xc, xz, dbc, Wdt, bdt, A_log, D, (int)B, (int)L, (int)C, (int)ED, (int)H, nullptr,
@@ -1436,7 +1506,14 @@ extern "C" int hmx_scan_bwd(const float* xc, const float* xz, const float* dbc, 
     q.par_part = par_part;
     q.GPH = (int)hmx_scan_groups_per_head(ED);
     const dim3 grid((unsigned)B, (unsigned)hmx_ceil_div(C, 256));
-    const size_t lds = (size_t)kScanChunk * H * kP * 4;
+    const size_t lds = (size_t)kCk * 4 * 256 * sizeof(float4) + (size_t)kScanChunkBwd * H * kP * 4;
+    static const hipError_t attr64 = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_kernel<64>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const hipError_t attr32 = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_kernel<32>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr64;
+    (void)attr32;
+    if (lds > 160 * 1024) return HMX_EINVAL;
     if (ED >= 64) hipLaunchKernelGGL(scan_bwd_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, q);
     else hipLaunchKernelGGL(scan_bwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, q);
     HMX_CHECK_LAUNCH();

@@ -74,6 +74,45 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const float* __rest
     }
 }
 
+// Row gather with the copy rounded to bf16 on the way out (round to nearest even, v_cvt_pk_bf16_f32): the read
+// side is the same random 16-byte-per-lane row fetch, the write stream is half as wide (8 bytes per lane).
+// d % 4 == 0, 16-byte aligned table, 8-byte aligned output.
+__global__ __launch_bounds__(kBlock) void gather_rows_bf16_kernel(const float* __restrict__ table, int64_t rows, int cpr,
+                                                                  int lpr_log2, const int64_t* __restrict__ ids,
+                                                                  int64_t n, uint2* __restrict__ out) {
+    const int lpr = 1 << lpr_log2;
+    const int lane_c = threadIdx.x & (lpr - 1);
+    const int rows_per_block = kBlock >> lpr_log2;
+    const int64_t row_stride = (int64_t)gridDim.x * rows_per_block * kUnroll;
+    for (int64_t base = (int64_t)blockIdx.x * rows_per_block * kUnroll + (threadIdx.x >> lpr_log2); base < n;
+         base += row_stride) {
+        const float4* src[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t r = base + (int64_t)u * rows_per_block;
+            src[u] = nullptr;
+            if (r < n) {
+                const int64_t id = ids[r];
+                if (id >= 0 && id < rows) src[u] = reinterpret_cast<const float4*>(table) + id * cpr;
+            }
+        }
+        for (int c = lane_c; c < cpr; c += lpr) {
+            float4 v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = src[u] ? src[u][c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int64_t r = base + (int64_t)u * rows_per_block;
+                if (r < n) {
+                    using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+                    const u32x2 o = {hmx_pack_bf16x2(v[u].x, v[u].y), hmx_pack_bf16x2(v[u].z, v[u].w)};
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(out) + r * cpr + c);
+                }
+            }
+        }
+    }
+}
+
 template <bool ROUTED, bool GELU = false>
 int launch_gather(const float* t0, int64_t r0, const float* t1, int64_t r1, int64_t d, const int64_t* ids,
                   const int64_t* tt, int64_t n, float* out, hipStream_t s) {
@@ -104,6 +143,26 @@ extern "C" int hmx_gather_rows_f32(const float* table, int64_t n_rows, int64_t d
     if (n < 0 || d <= 0 || n_rows <= 0) return HMX_EINVAL;
     if (n > 0 && (!table || !ids || !out)) return HMX_EINVAL;
     return launch_gather<false>(table, n_rows, nullptr, 0, d, ids, nullptr, n, out, (hipStream_t)stream);
+}
+
+extern "C" int hmx_gather_rows_bf16(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n,
+                                    uint16_t* out, void* stream) {
+    HMX_ENTER();
+    if (n < 0 || d <= 0 || n_rows <= 0 || d % 4 != 0) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!table || !ids || !out || reinterpret_cast<uintptr_t>(table) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 8 != 0)
+        return HMX_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t cpr = d / 4;
+    const int l2 = lpr_log2_for(cpr);
+    const int64_t rows_per_block = (kBlock >> l2) * kUnroll;
+    const int grid = (int)std::min<int64_t>(hmx_ceil_div(n, rows_per_block), kMaxGrid);
+    void* span = hmx_profile_begin("gather_rows_bf16", s);
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(grid), dim3(kBlock), 0, s, table, n_rows, (int)cpr, l2, ids, n,
+                       reinterpret_cast<uint2*>(out));
+    hmx_profile_end(span, s);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
 }
 
 extern "C" int hmx_gather_gelu_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n,

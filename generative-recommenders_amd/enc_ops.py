@@ -339,7 +339,7 @@ class _Scan(torch.autograd.Function):
         if ED < 32 or ED & (ED - 1) or C != ED * H:
             raise hmx.HmxError(f"selective scan needs 4*head_dim to be a power of two >= 32 (got {ED})")
         keep = any(ctx.needs_input_grad)
-        hs = _empty(T, C, N_STATE, like=xc) if keep else None
+        hs = _empty(max(int(_L().hmx_scan_state_floats(B, L, C)), 1), like=xc) if keep else None
         yg = torch.empty_like(xc)
         hmx.check(_L().hmx_scan_fwd(hmx.ptr(xc), hmx.ptr(z), hmx.ptr(dbc), hmx.ptr(Wdt), hmx.ptr(bdt), hmx.ptr(A_log),
                                     hmx.ptr(D), B, L, C, ED, H, hmx.ptr(yg), hmx.ptr(hs), _s()), "hmx_scan_fwd")

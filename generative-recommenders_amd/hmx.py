@@ -18,6 +18,7 @@ PROTOTYPES = {
     "hmx_abi_version": (c_int, []),
     "hmx_error_string": (c_char_p, [c_int]),
     "hmx_gather_rows_f32": (c_int, [P, I64, I64, P, I64, P, P]),
+    "hmx_gather_rows_bf16": (c_int, [P, I64, I64, P, I64, P, P]),
     "hmx_gather_routed_f32": (c_int, [P, I64, P, I64, I64, P, P, I64, P, P]),
     "hmx_gather_gelu_rows_f32": (c_int, [P, I64, I64, P, I64, P, P]),
     "hmx_scatter_add_rows_workspace_bytes": (c_size_t, [I64, I64, I64]),
@@ -57,6 +58,7 @@ PROTOTYPES = {
     "hmx_conv_silu_bwd": (c_int, [P, P, P, P, I64, I64, I64, P, P, P]),
     "hmx_scan_fwd": (c_int, [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P]),
     "hmx_scan_groups_per_head": (I64, [I64]),
+    "hmx_scan_state_floats": (I64, [I64, I64, I64]),
     "hmx_scan_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, P]),
     "hmx_sum_groups_f32": (c_int, [P, I64, I64, I64, P, P]),
     "hmx_profile_enable": (c_int, [c_int]),

@@ -115,6 +115,19 @@ def gather_rows(weight, ids, padding_idx=None):
 
 
 @torch.no_grad()
+def gather_rows_bf16(weight, ids):
+    """out[..., :] = bf16(weight[ids[...], :]) (round to nearest even) as a torch.bfloat16 tensor; no gradient."""
+    _need_cuda(weight, ids)
+    w = _f32c(weight.detach())
+    idc = _i64c(ids)
+    _validate_ids(idc, w.shape[0], "gather_rows_bf16")
+    out = torch.empty(*idc.shape, w.shape[1], dtype=torch.bfloat16, device=w.device)
+    hmx.check(hmx.lib().hmx_gather_rows_bf16(hmx.ptr(w), w.shape[0], w.shape[1], hmx.ptr(idc), idc.numel(),
+                                             hmx.ptr(out), hmx.current_stream()), "hmx_gather_rows_bf16")
+    return out
+
+
+@torch.no_grad()
 def gather_gelu_rows(weight, ids):
     """out[..., :] = GELU(weight[ids[...], :]) in one pass (candidate-embedding generation; no gradient)."""
     _need_cuda(weight, ids)

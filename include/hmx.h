@@ -45,6 +45,13 @@ const char* hmx_error_string(int code);
 int hmx_gather_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n, float* out,
                         void* stream);
 
+/* The same gather with the copy rounded to bf16 (round to nearest even) as it is written: out[i, :] =
+ * bf16(table[ids[i], :]), for consumers that feed the rows to a bf16 MFMA product anyway (scoring tables, the
+ * single-bf16 projection mode).  The write stream is half as wide.  d % 4 == 0; no backward (use the f32 form under
+ * autograd).  Same id handling as hmx_gather_rows_f32. */
+int hmx_gather_rows_bf16(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n, uint16_t* out,
+                         void* stream);
+
 /* Token-type routed gather (embedding.py:436-450):
  *   out[i] = item_table[ids[i]] if token_type[i]==1, user_table[ids[i]] if ==2, else 0. */
 int hmx_gather_routed_f32(const float* item_table, int64_t item_rows, const float* user_table, int64_t user_rows,
@@ -260,11 +267,13 @@ int hmx_pscan_bwd(const float* A, const float* H, const float* dH, int64_t B, in
 
 /* Selective scan of all heads (hydra3.py:107-123, 203-214) fused with the dt projection + softplus
  * (:210) and the SiLU(z) gate (:273).  C = H * ED channels, ED a power of two >= 32, state N = 16,
- * dt rank 16.  dbc (T, H, 48) = [dt_rank | B | C] rows of deltaBC_layer.  hs (T * C * 16 floats), if not NULL,
- * receives every state for the backward pass in the kernels' own order ([t][n / 4][c][n % 4]: opaque to callers,
- * to be handed to hmx_scan_bwd unchanged).  Backward writes dxc, dz, per-group partials of d(dbc)
+ * dt rank 16.  dbc (T, H, 48) = [dt_rank | B | C] rows of deltaBC_layer.  hs (hmx_scan_state_floats(B, L, C)
+ * floats), if not NULL, receives state checkpoints for the backward pass (one every four steps, in the kernels' own
+ * order: opaque to callers, to be handed to hmx_scan_bwd unchanged; the backward pass recomputes the states in
+ * between instead of reading them back).  Backward writes dxc, dz, per-group partials of d(dbc)
  * shaped (T, H, hmx_scan_groups_per_head(ED), 48) (sum with hmx_sum_groups_f32) and per-sequence
  * parameter partials par_part (B, C, 34) = [dA_log(16) | dW_dt(16) | db_dt | dD]. */
+int64_t hmx_scan_state_floats(int64_t B, int64_t L, int64_t C);
 int hmx_scan_fwd(const float* xc, const float* z, const float* dbc, const float* Wdt, const float* bdt,
                  const float* A_log, const float* D, int64_t B, int64_t L, int64_t C, int64_t ED, int64_t H, float* yg,
                  float* hs, void* stream);
@@ -278,7 +287,7 @@ int hmx_sum_groups_f32(const float* part, int64_t rows, int64_t groups, int64_t 
  * Benchmark support (no counterpart in the reference).  When enabled, entry points bracket
  * their dominant kernel with HIP events on the caller's stream; hmx_profile_collect blocks
  * until the events of spans tagged `tag` have completed, returns their summed duration and
- * count, and forgets them.  Tags: "topk_coarse_bf16", "topk_coarse_f32", "gather_rows", "scatter_segment_sum".
+ * count, and forgets them.  Tags: "topk_coarse_bf16", "topk_coarse_f32", "gather_rows", "gather_rows_bf16", "scatter_segment_sum".
  * ------------------------------------------------------------------------------- */
 int hmx_profile_enable(int on);
 int hmx_profile_collect(const char* tag, double* total_ms, int64_t* launches);

@@ -27,6 +27,18 @@ def test_gather_bit_exact(rows, d, shape):
     assert np.array_equal(out.cpu().numpy(), C.gather_rows(t.numpy(), ids.numpy()))
 
 
+@pytest.mark.parametrize("rows,d,shape", [(1000, 64, (37, 100)), (50, 128, (2, 3, 4)), (100, 16, (3,)), (300, 20, (11,))])
+def test_gather_bf16_is_the_rounded_exact_copy(rows, d, shape):
+    """bf16 output = round-to-nearest-even of the gathered fp32 rows (PyTorch's CPU conversion as the rounding
+    reference), bit for bit; out-of-range ids read as zero rows."""
+    t = _table(rows, d, 11)
+    ids = torch.randint(-2, rows + 2, shape, generator=torch.Generator().manual_seed(12))
+    out = ops.gather_rows_bf16(t.to(DEV), ids.to(DEV))
+    assert out.dtype == torch.bfloat16 and out.shape == shape + (d,)
+    want = torch.from_numpy(C.gather_rows(t.numpy(), ids.numpy())).bfloat16()
+    assert torch.equal(out.cpu().view(torch.int16), want.view(torch.int16))
+
+
 def test_gather_out_of_range_ids_read_zero():
     t = _table(10, 64, 3)
     ids = torch.tensor([1, -1, 10, 9, 2 ** 40])
