@@ -7,6 +7,7 @@
 // registers and walks the sequence; everything pointwise (SiLU, RoPE, gates, conv, RMSNorm) is
 // fused into a handful of streaming kernels.
 #include <algorithm>
+#include <atomic>
 
 #include "hmx_common.h"
 
@@ -376,93 +377,180 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
 
 // ---------------------------------------------------------------------------- weight gradient (fp32 MFMA)
 // part[s][n][k] = sum_{t in split s} dY[t][n] * X[t][k] * in_rowmask[t];  column K (if with_bias) = sum_t dY[t][n].
-struct WgradParams {
+// One weight-gradient product of a batched launch.
+struct WgradJob {
     const float* dY;
-    int64_t ldy;
     const float* X;
-    int64_t ldx;
     const float* in_rowmask;
-    int64_t T, tok_per_split;
-    int N, K, with_bias;
-    float* part;
+    float* dW;
+    float* dbias;
+    int64_t ldy, ldx, ldw, T;
+    int N, K, with_bias, accumulate;
+    int tile0;               // first global tile of this job
+};
+constexpr int kWgradMaxJobs = 24;
+struct WgradParams {
+    WgradJob job[kWgradMaxJobs];
+    int n_jobs;
+    float* part;             // slabs [global tile][group][16 x 64]
+    unsigned* tickets;       // one arrival counter per global tile, zero on entry and on exit
 };
 
-__global__ __launch_bounds__(64) void wgrad_kernel(WgradParams p) {
-    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    const int kx = p.K + (p.with_bias ? 1 : 0);
+// Arrival counters of the in-launch reduction below: one word per output tile of a launch, in a slot chosen by the
+// host per call.  They are zero whenever no launch is in flight: the workgroup that arrives last puts its counter
+// back to zero.  (Concurrent launches from several streams take different slots, sixteen of them.)
+constexpr int kWgradMaxTiles = 1024;
+constexpr int kWgradSlots = 16;
+__device__ unsigned g_wgrad_tickets[kWgradSlots * kWgradMaxTiles];
+
+// Weight gradients of up to kWgradMaxJobs projections in one launch.  blockIdx.y walks the 32 x 32 output tiles of
+// all jobs, blockIdx.x the token-split groups.  One workgroup = four waves = four consecutive token splits of ONE
+// tile.  A wave runs trips of kSteps MFMA steps (2 tokens each) with the loads of the next trip issued before the
+// MFMAs of this one.  The four partial tiles are added in LDS (wave order) and written as one slab; the workgroup
+// that arrives last at the tile's counter adds the slabs in group order and writes (or adds to) dW / dbias: fixed
+// association order, no float atomics, no second launch.
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+    __shared__ float sh[4][16][64];
+    __shared__ unsigned sh_ticket;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int gtile = blockIdx.y;
+    int ji = 0;
+    while (ji + 1 < p.n_jobs && p.job[ji + 1].tile0 <= gtile) ++ji;     // wave-uniform scan of at most 24 entries
+    const WgradJob& jb = p.job[ji];
+    const int tile = gtile - jb.tile0;
+    const int kx = jb.K + (jb.with_bias ? 1 : 0);
     const int kt_n = (kx + 31) / 32;
-    const int nt = blockIdx.y / kt_n, kt = blockIdx.y % kt_n;
+    const int nt = tile / kt_n, kt = tile % kt_n;
     const int n = nt * 32 + i, kc = kt * 32 + i;
-    const int64_t t0 = (int64_t)blockIdx.x * p.tok_per_split;
-    const int64_t t1 = min(p.T, t0 + p.tok_per_split);
+    const int n_groups = gridDim.x;
+    int64_t tps = hmx_ceil_div(jb.T, (int64_t)n_groups * 4);
+    tps += tps & 1;
+    const int64_t t0 = min(jb.T, ((int64_t)blockIdx.x * 4 + wave) * tps);
+    const int64_t t1 = min(jb.T, t0 + tps);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool n_ok = n < p.N;
-    const int kind = kc < p.K ? 0 : ((kc == p.K && p.with_bias) ? 1 : 2);
-    int64_t t = t0;
-    constexpr int kSteps = 16;      // MFMA steps per trip; their 2 * kSteps loads are issued together
-    for (; t + 2 * kSteps <= t1; t += 2 * kSteps) {
-        float a[kSteps], b[kSteps];
+    const bool n_ok = n < jb.N;
+    const int kind = kc < jb.K ? 0 : ((kc == jb.K && jb.with_bias) ? 1 : 2);
+    constexpr int kSteps = 8;
+    const float* ap = jb.dY + (n_ok ? n : 0);
+    const float* bp = jb.X + (kind == 0 ? kc : 0);
+    const float* mp = jb.in_rowmask;
+    const int64_t ldy = jb.ldy, ldx = jb.ldx;
+    auto load_trip = [&](float(&a)[kSteps], float(&b)[kSteps], int64_t t) {   // tokens t .. t + 2 kSteps - 1, all < t1
 #pragma unroll
         for (int u = 0; u < kSteps; ++u) {
             const int64_t tt = t + 2 * u + h;
-            a[u] = n_ok ? p.dY[tt * p.ldy + n] : 0.f;
-            b[u] = kind == 1 ? 1.f : 0.f;
-            if (kind == 0) {
-                b[u] = p.X[tt * p.ldx + kc];
-                if (p.in_rowmask) b[u] *= p.in_rowmask[tt];
-            }
+            a[u] = ap[tt * ldy];
+            b[u] = bp[tt * ldx];
         }
+        if (mp != nullptr) {
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+            for (int u = 0; u < kSteps; ++u) b[u] *= mp[t + 2 * u + h];
+        }
+    };
+    auto mfma_trip = [&](const float(&a)[kSteps], const float(&b)[kSteps]) {
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(n_ok ? a[u] : 0.f, kind == 0 ? b[u] : (kind == 1 ? 1.f : 0.f), acc, 0, 0, 0);
+    };
+    int64_t t = t0;
+    const int64_t n_trips = (t1 - t0) / (2 * kSteps);
+    if (n_trips > 0) {
+        float a0[kSteps], b0[kSteps], a1[kSteps], b1[kSteps];
+        load_trip(a0, b0, t);
+        int64_t trip = 0;
+        for (; trip + 2 < n_trips; trip += 2) {     // both buffers reloaded unconditionally inside the loop
+            load_trip(a1, b1, t + 2 * kSteps);
+            mfma_trip(a0, b0);
+            load_trip(a0, b0, t + 4 * kSteps);
+            mfma_trip(a1, b1);
+            t += 4 * kSteps;
+        }
+        if (trip + 1 < n_trips) {                   // two trips left
+            load_trip(a1, b1, t + 2 * kSteps);
+            mfma_trip(a0, b0);
+            mfma_trip(a1, b1);
+            t += 4 * kSteps;
+        } else {                                    // one trip left
+            mfma_trip(a0, b0);
+            t += 2 * kSteps;
+        }
     }
     for (; t < t1; t += 2) {
         const int64_t tt = t + h;
         const bool ok = tt < t1;
-        const float a = (ok && n_ok) ? p.dY[tt * p.ldy + n] : 0.f;
+        const float a = (ok && n_ok) ? jb.dY[tt * ldy + n] : 0.f;
         float b = 0.f;
         if (ok) {
             if (kind == 0) {
-                b = p.X[tt * p.ldx + kc];
-                if (p.in_rowmask) b *= p.in_rowmask[tt];
+                b = jb.X[tt * ldx + kc];
+                if (mp) b *= mp[tt];
             } else if (kind == 1) {
                 b = 1.f;
             }
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
-    if (kc < kx) {
+    // the four waves' tiles, added in wave order
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int nr = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (nr < p.N) p.part[((int64_t)blockIdx.x * p.N + nr) * kx + kc] = acc[r];
-        }
-    }
-}
-
-// dW[n * ldw + k] = sum_s part[s][n][k];  db[n] = sum_s part[s][n][K].
-// Block = 16 outputs x 16 split lanes: lane g sums splits g, g + 16, ... in order, then the 16 partial sums are
-// added in lane order (fixed association, so the result does not depend on timing).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int n_splits, int N, int K,
-                                                           int kx, float* __restrict__ dW, int64_t ldw,
-                                                           float* __restrict__ db) {
-    __shared__ float sh[16][17];
-    const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + o;
-    float s = 0.f;
-    if (idx < N * kx)
-        for (int sp = g; sp < n_splits; sp += 16) s += part[(int64_t)sp * N * kx + idx];
-    sh[g][o] = s;
+    for (int r = 0; r < 16; ++r) sh[wave][r][lane] = acc[r];
     __syncthreads();
-    if (g == 0 && idx < N * kx) {
-        float t = sh[0][o];
+    const int e0 = threadIdx.x * 4;              // this thread's four consecutive elements of the [16][64] tile image
+    const float* s0 = &sh[0][0][0] + e0;
+    float4 v = *reinterpret_cast<const float4*>(s0);
 #pragma unroll
-        for (int j = 1; j < 16; ++j) t += sh[j][o];
-        const int n = idx / kx, k = idx % kx;
-        if (k < K) dW[(int64_t)n * ldw + k] = t;
-        else if (db) db[n] = t;
+    for (int w = 1; w < 4; ++w) {
+        const float4 o = *reinterpret_cast<const float4*>(s0 + w * 1024);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
+    float4* slabs = reinterpret_cast<float4*>(p.part) + (int64_t)gtile * n_groups * 256;
+    auto finish = [&](const float4& tot) {       // element e = r * 64 + lane_e of the tile image -> (n, k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q, r = e >> 6, le = e & 63;
+            const int nr = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5), kk = kt * 32 + (le & 31);
+            const float val = q == 0 ? tot.x : q == 1 ? tot.y : q == 2 ? tot.z : tot.w;
+            if (nr < jb.N) {
+                float* dst = kk < jb.K ? jb.dW + (int64_t)nr * jb.ldw + kk : ((kk == jb.K && jb.with_bias) ? jb.dbias + nr : nullptr);
+                if (dst != nullptr) *dst = jb.accumulate ? *dst + val : val;
+            }
+        }
+    };
+    if (n_groups == 1) {
+        finish(v);
+        return;
+    }
+    slabs[(int64_t)blockIdx.x * 256 + threadIdx.x] = v;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh_ticket = __hip_atomic_fetch_add(p.tickets + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (sh_ticket != (unsigned)(n_groups - 1)) return;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(p.tickets + gtile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    int g = 0;
+    for (; g + 8 <= n_groups; g += 8) {          // eight slabs requested together, added in group order
+        float4 o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = slabs[(int64_t)(g + u) * 256 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { tot.x += o[u].x; tot.y += o[u].y; tot.z += o[u].z; tot.w += o[u].w; }
+    }
+    for (; g < n_groups; ++g) {
+        const float4 o = slabs[(int64_t)g * 256 + threadIdx.x];
+        tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
+    }
+    finish(tot);
 }
 
 // ---------------------------------------------------------------------------- pointwise kernels
@@ -1132,40 +1220,90 @@ extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64
     return HMX_OK;
 }
 
-// Token splits of the weight-gradient product: one wave per (split, 32x32 output tile).  Enough splits to put
-// about 2048 waves on the chip (the loop per wave is a dependent load -> MFMA chain), at least 128 tokens each.
-static int64_t wgrad_splits(int64_t T, int64_t N, int64_t K) {
-    const int64_t tiles = hmx_ceil_div(N, 32) * hmx_ceil_div(K + 1, 32);
-    int64_t s = hmx_ceil_div(2048, tiles);
-    s = std::min<int64_t>(s, hmx_ceil_div(T, 128));
-    return std::max<int64_t>(1, std::min<int64_t>(s, 512));
+// Token splits of a weight-gradient launch: four per workgroup (one per wave), enough workgroups to put about two
+// thousand waves on the chip, at least 64 tokens per wave.
+static int64_t wgrad_groups(int64_t T_max, int64_t tiles) {
+    int64_t g = hmx_ceil_div(hmx_ceil_div(2048, tiles), 4);
+    g = std::min<int64_t>(g, hmx_ceil_div(T_max, 4 * 64));
+    return std::max<int64_t>(1, std::min<int64_t>(g, 128));
+}
+static int64_t wgrad_tiles(int64_t N, int64_t K, bool with_bias) {
+    return hmx_ceil_div(N, 32) * hmx_ceil_div(K + (with_bias ? 1 : 0), 32);
+}
+
+static int wgrad_tickets_for_call(unsigned** out) {
+    static std::atomic<unsigned> next_slot{0};
+    static std::atomic<unsigned*> ticket_base[64];      // per device: each GPU has its own copy of the array
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return HMX_ELAUNCH;
+    unsigned* tickets = ticket_base[dev].load();
+    if (tickets == nullptr) {
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&tickets), HIP_SYMBOL(g_wgrad_tickets)) != hipSuccess || !tickets)
+            return HMX_ELAUNCH;
+        ticket_base[dev].store(tickets);
+    }
+    *out = tickets + (size_t)(next_slot.fetch_add(1) % kWgradSlots) * kWgradMaxTiles;
+    return HMX_OK;
+}
+
+extern "C" size_t hmx_linear_wgrad_batch_workspace_bytes(const hmx_wgrad_desc* descs, int64_t n) {
+    int64_t tiles = 0, t_max = 1;
+    for (int64_t j = 0; j < n; ++j) {
+        tiles += wgrad_tiles(descs[j].N, descs[j].K, descs[j].dbias != nullptr);
+        t_max = std::max<int64_t>(t_max, descs[j].T);
+    }
+    if (tiles == 0) return 256;
+    return (size_t)wgrad_groups(t_max, tiles) * tiles * 1024 * sizeof(float) + 256;
+}
+
+extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    HMX_ENTER();
+    if (n == 0) return HMX_OK;
+    if (!descs || n < 0 || n > kWgradMaxJobs || !workspace) return HMX_EINVAL;
+    if (workspace_bytes < hmx_linear_wgrad_batch_workspace_bytes(descs, n)) return HMX_EWORKSPACE;
+    WgradParams p{};
+    int64_t tiles = 0, t_max = 1;
+    int nj = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const hmx_wgrad_desc& d = descs[j];
+        if (d.N == 0 || d.K == 0) continue;
+        if (!d.dY || !d.X || !d.dW || d.T <= 0 || d.N < 0 || d.K < 0) return HMX_EINVAL;
+        WgradJob& jb = p.job[nj++];
+        jb.dY = d.dY; jb.X = d.X; jb.in_rowmask = d.in_rowmask; jb.dW = d.dW; jb.dbias = d.dbias;
+        jb.ldy = d.ldy; jb.ldx = d.ldx; jb.ldw = d.ldw; jb.T = d.T;
+        jb.N = (int)d.N; jb.K = (int)d.K; jb.with_bias = d.dbias != nullptr; jb.accumulate = d.accumulate != 0;
+        jb.tile0 = (int)tiles;
+        tiles += wgrad_tiles(d.N, d.K, d.dbias != nullptr);
+        t_max = std::max<int64_t>(t_max, d.T);
+    }
+    if (nj == 0) return HMX_OK;
+    if (tiles > kWgradMaxTiles) return HMX_EINVAL;
+    p.n_jobs = nj;
+    p.part = static_cast<float*>(workspace);
+    const int rc = wgrad_tickets_for_call(&p.tickets);
+    if (rc != HMX_OK) return rc;
+    const int64_t G = wgrad_groups(t_max, tiles);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)G, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
 }
 
 extern "C" size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K) {
-    return (size_t)wgrad_splits(T, N, K) * N * (K + 1) * sizeof(float) + 256;
+    hmx_wgrad_desc d{};
+    d.T = T; d.N = N; d.K = K;
+    d.dbias = reinterpret_cast<float*>(1);      // size for the variant with a bias column
+    return hmx_linear_wgrad_batch_workspace_bytes(&d, 1);
 }
 
 extern "C" int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, const float* in_rowmask,
                                     int64_t T, int64_t N, int64_t K, float* dW, int64_t ldw, float* dbias,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-    HMX_ENTER();
     if (N == 0 || K == 0) return HMX_OK;
     if (!dY || !X || !dW || !workspace || T <= 0) return HMX_EINVAL;
     if (workspace_bytes < hmx_linear_wgrad_workspace_bytes(T, N, K)) return HMX_EWORKSPACE;
-    const int64_t S = wgrad_splits(T, N, K);
-    const int with_bias = dbias != nullptr;
-    const int kx = (int)K + with_bias;
-    int64_t tps = hmx_ceil_div(T, S);
-    tps += tps & 1;
-    WgradParams p{dY, ldy, X, ldx, in_rowmask, T, tps, (int)N, (int)K, with_bias, (float*)workspace};
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)S, (unsigned)(hmx_ceil_div(N, 32) * hmx_ceil_div(kx, 32))), dim3(64), 0,
-                       s, p);
-    HMX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)hmx_ceil_div(N * kx, 16)), dim3(256), 0, s,
-                       (const float*)workspace, (int)S, (int)N, (int)K, kx, dW, ldw, dbias);
-    HMX_CHECK_LAUNCH();
-    return HMX_OK;
+    hmx_wgrad_desc d{dY, ldy, X, ldx, in_rowmask, T, N, K, dW, ldw, dbias, 0};
+    return hmx_linear_wgrad_batch_f32(&d, 1, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------- plain linear recurrence

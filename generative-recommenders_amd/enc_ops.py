@@ -107,6 +107,132 @@ def rmsnorm(x, scale, eps=1e-6):
     return _RMSNorm.apply(x, scale, eps)
 
 
+# ------------------------------------------------------------------------------- deferred weight gradients
+# Opt-in (set_direct_param_grad): the weight / bias gradients of the projections are not returned to autograd one
+# launch at a time; their operands are queued and up to 24 products run as ONE launch that adds straight into
+# `param.grad`.  Same sums (fp32 MFMA, fixed order per launch shape); a backward pass of the encoder then has a dozen
+# weight-gradient launches instead of some 180.  Like ops.set_fused_table_grad it bypasses autograd's accumulation,
+# so torch.autograd.grad() does not see these gradients; leave it off there.
+_DIRECT_PARAM_GRAD = False
+_WGRAD_BATCH = 24
+
+
+def set_direct_param_grad(flag=True):
+    global _DIRECT_PARAM_GRAD
+    _wgrad_queue.flush()
+    _DIRECT_PARAM_GRAD = bool(flag)
+
+
+class GradArena:
+    """One flat zero-filled buffer per backward pass for the gradients of a module's dense parameters: `.grad`
+    tensors are views into it, created when a parameter first receives a gradient (parameters that receive none
+    keep grad = None, as under plain autograd).  One fill instead of one per parameter."""
+
+    def __init__(self, params):
+        import weakref
+        self.offsets, self.total = {}, 0
+        for q in params:
+            self.offsets[id(q)] = (self.total, q.numel(), weakref.ref(q))   # id() alone could be a recycled one
+            self.total += (q.numel() + 63) // 64 * 64
+        self.buf = None
+        self.views = []
+
+    def alive(self):
+        return any(slot[2]() is not None for slot in self.offsets.values())
+
+    def target(self, param):
+        slot = self.offsets.get(id(param))
+        if slot is None or slot[2]() is not param:
+            return None
+        # a new buffer once every view of the old one has been dropped (zero_grad(set_to_none=True))
+        if self.buf is None or all(v() is None for v in self.views) or self.buf.device != param.device:
+            self.buf = torch.zeros(self.total, dtype=torch.float32, device=param.device)
+            self.views = []
+        g = self.buf[slot[0]:slot[0] + slot[1]].view(param.shape)
+        import weakref
+        self.views.append(weakref.ref(g))
+        return g
+
+
+_ARENAS = []
+
+
+def register_grad_arena(module, exclude=()):
+    """Dense (non-table) parameters of `module` get their .grad from one flat buffer in direct-gradient mode."""
+    skip = {id(q) for q in exclude}
+    arena = GradArena([q for q in module.parameters() if id(q) not in skip])
+    _ARENAS[:] = [a for a in _ARENAS if a.alive()]
+    _ARENAS.append(arena)
+    return arena
+
+
+def _param_grad_target(param):
+    """The tensor a direct weight gradient is added into (created zero-filled if the parameter has none yet), or None
+    when the standard autograd path applies."""
+    if not (_DIRECT_PARAM_GRAD and isinstance(param, torch.nn.Parameter) and param.is_leaf and param.requires_grad
+            and param.dtype == torch.float32 and param.is_contiguous()):
+        return None
+    if param.grad is None:
+        g = None
+        for arena in _ARENAS:
+            g = arena.target(param)
+            if g is not None:
+                break
+        param.grad = g if g is not None else torch.zeros_like(param)
+    g = param.grad
+    return g if (g.is_contiguous() and g.dtype == torch.float32 and g.device == param.device) else None
+
+
+class _WgradQueue:
+    def __init__(self):
+        self.jobs, self.keep, self.targets, self.armed = [], [], set(), False
+
+    def add(self, dy, dy_off, ldy, x, x_off, ldx, in_mask, T, N, K, dw, dw_off, ldw, db, db_off):
+        """dW[dw_off ...] += dY^T X (and dbias += column sums of dY); offsets are in elements."""
+        tw = dw.data_ptr() + 4 * dw_off
+        tb = db.data_ptr() + 4 * db_off if db is not None else None
+        if tw in self.targets or (tb is not None and tb in self.targets) or len(self.jobs) >= _WGRAD_BATCH:
+            self.flush()
+        d = hmx.WgradDesc(dy.data_ptr() + 4 * dy_off, ldy, x.data_ptr() + 4 * x_off, ldx,
+                          in_mask.data_ptr() if in_mask is not None else None, T, N, K, tw, ldw, tb, 1)
+        self.jobs.append(d)
+        self.keep.append((dy, x, in_mask, dw, db))
+        self.targets.add(tw)
+        if tb is not None:
+            self.targets.add(tb)
+        self.stream = _s()
+        self.device = dy.device
+        if not self.armed:
+            try:   # runs when the backward pass that is executing now has finished
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self.armed = True
+            except RuntimeError:
+                self.flush()          # not inside a backward pass: nothing to wait for
+
+    def _end_of_backward(self):
+        self.armed = False
+        self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        n = len(self.jobs)
+        arr = (hmx.WgradDesc * n)(*self.jobs)
+        nbytes = _L().hmx_linear_wgrad_batch_workspace_bytes(arr, n)
+        ws = workspace(nbytes, self.device)
+        rc = _L().hmx_linear_wgrad_batch_f32(arr, n, hmx.ptr(ws), ws.numel(), self.stream)
+        self.jobs, self.keep, self.targets = [], [], set()
+        hmx.check(rc, "hmx_linear_wgrad_batch_f32")
+
+
+_wgrad_queue = _WgradQueue()
+
+
+def flush_deferred_wgrads():
+    """Run the queued weight-gradient products now (a backward pass does this by itself when it ends)."""
+    _wgrad_queue.flush()
+
+
 # ------------------------------------------------------------------------------- linear
 def _linear_raw(x_ptr, ldx, w_ptr, w_rs, w_cs, bias, T, N, K, y_ptr, ldy, r1=None, c1=0.0, r2=None, c2=0.0,
                 in_mask=None, out_mask=None, accumulate=False):
@@ -140,6 +266,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, w, in_mask, out_mask)
         ctx.c = (c1, c2)
         ctx.has_bias = bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
         return y
 
     @staticmethod
@@ -156,11 +283,18 @@ class _Linear(torch.autograd.Function):
             dx = _empty(T, K, like=x)
             _linear_raw(hmx.ptr(g), N, hmx.ptr(w), 1, ldw, None, T, K, N, hmx.ptr(dx), K, out_mask=in_mask)
         want_db = ctx.has_bias and need[2]
-        if need[1]:
+        tw = _param_grad_target(ctx.wparam) if need[1] else None
+        tb = _param_grad_target(ctx.bparam) if want_db else None
+        if tw is not None and (tb is not None or not want_db):
+            # direct mode: queued, added into .grad by a batched launch; nothing is returned to autograd
+            _wgrad_queue.add(g, 0, N, x, 0, K, in_mask, T, N, K, tw, 0, ldw, tb, 0)
+            want_db = False
+        elif need[1]:
             dw = torch.zeros_like(w) if ldw > K else torch.empty_like(w)
             db = _empty(N, like=x) if want_db else None
             _wgrad_raw(hmx.ptr(g), N, hmx.ptr(x), K, in_mask, T, N, K, hmx.ptr(dw), ldw, db, x.device)
-        elif want_db:            # frozen weight, trainable bias: the bias gradient is the column sum of dy
+            want_db = False
+        if want_db:              # frozen weight, trainable bias: the bias gradient is the column sum of dy
             db = colsum(g)
         if need[5]:
             dr1 = g if ctx.c[0] == 1.0 else combine([g], [ctx.c[0]])
@@ -175,13 +309,14 @@ def linear(x, weight, bias=None, in_mask=None, out_mask=None, r1=None, c1=0.0, r
 
 
 class _HeadsLinear(torch.autograd.Function):
-    """Block-diagonal projection: y[:, h*n_out:(h+1)*n_out] = x[:, h*k_in:(h+1)*k_in] W_h^T for every head h."""
+    """Block-diagonal projection: y[:, h*n_out:(h+1)*n_out] = x[:, h*k_in:(h+1)*k_in] W_h^T for every head h, with
+    W_h = params[h][r0:r1] (rows r0..r1 of that head's parameter)."""
 
     @staticmethod
-    def forward(ctx, x, *weights):
+    def forward(ctx, x, r0, r1, *params):
         _need_cuda(x)
         x = _f32c(x)
-        ws = [_f32c(w) for w in weights]
+        ws = [_f32c(q)[r0:r1] for q in params]
         H = len(ws)
         n_out, k_in = ws[0].shape
         T = x.shape[0]
@@ -191,6 +326,7 @@ class _HeadsLinear(torch.autograd.Function):
             _linear_raw(x.data_ptr() + 4 * h * k_in, H * k_in, hmx.ptr(w), k_in, 1, None, T, n_out, k_in,
                         y.data_ptr() + 4 * h * n_out, H * n_out)
         ctx.save_for_backward(x, *ws)
+        ctx.params, ctx.rows = params, (r0, r1)
         return y
 
     @staticmethod
@@ -200,6 +336,7 @@ class _HeadsLinear(torch.autograd.Function):
         H = len(ws)
         n_out, k_in = ws[0].shape
         T = x.shape[0]
+        r0, r1 = ctx.rows
         dx = _empty(T, H * k_in, like=x) if ctx.needs_input_grad[0] else None
         dws = []
         for h, w in enumerate(ws):
@@ -207,18 +344,28 @@ class _HeadsLinear(torch.autograd.Function):
             if dx is not None:
                 _linear_raw(gp, H * n_out, hmx.ptr(w), 1, k_in, None, T, k_in, n_out, dx.data_ptr() + 4 * h * k_in,
                             H * k_in)
-            if ctx.needs_input_grad[1 + h]:
-                dw = torch.empty_like(w)
-                _wgrad_raw(gp, H * n_out, x.data_ptr() + 4 * h * k_in, H * k_in, None, T, n_out, k_in, hmx.ptr(dw),
-                           k_in, None, x.device)
-                dws.append(dw)
-            else:
+            if not ctx.needs_input_grad[3 + h]:
                 dws.append(None)
-        return (dx, *dws)
+                continue
+            tw = _param_grad_target(ctx.params[h])
+            if tw is not None:
+                _wgrad_queue.add(g, h * n_out, H * n_out, x, h * k_in, H * k_in, None, T, n_out, k_in, tw, r0 * k_in,
+                                 k_in, None, 0)
+                dws.append(None)
+                continue
+            full = ctx.params[h]
+            dw = torch.zeros_like(full) if (r0, r1) != (0, full.shape[0]) else torch.empty_like(full)
+            _wgrad_raw(gp, H * n_out, x.data_ptr() + 4 * h * k_in, H * k_in, None, T, n_out, k_in,
+                       dw.data_ptr() + 4 * r0 * k_in, k_in, None, x.device)
+            dws.append(dw)
+        return (dx, None, None, *dws)
 
 
-def heads_linear(x, weights):
-    return _HeadsLinear.apply(x, *weights)
+def heads_linear(x, weights, rows=None):
+    """weights: one (n, k) parameter per head; rows = (r0, r1) restricts every head to those rows of its parameter
+    (the x / z halves of in_proj) without slicing the parameter under autograd."""
+    r0, r1 = rows if rows is not None else (0, weights[0].shape[0])
+    return _HeadsLinear.apply(x, r0, r1, *weights)
 
 
 # ------------------------------------------------------------------------------- pointwise

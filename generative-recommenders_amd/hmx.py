@@ -13,6 +13,13 @@ P = c_void_p
 I64 = c_int64
 F = c_float
 
+class WgradDesc(ctypes.Structure):
+    """hmx_wgrad_desc of include/hmx.h."""
+    _fields_ = [("dY", c_void_p), ("ldy", c_int64), ("X", c_void_p), ("ldx", c_int64), ("in_rowmask", c_void_p),
+                ("T", c_int64), ("N", c_int64), ("K", c_int64), ("dW", c_void_p), ("ldw", c_int64),
+                ("dbias", c_void_p), ("accumulate", c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/hmx.h
 PROTOTYPES = {
     "hmx_abi_version": (c_int, []),
@@ -48,6 +55,8 @@ PROTOTYPES = {
     "hmx_linear_f32": (c_int, [P, I64, P, I64, I64, P, I64, I64, I64, P, I64, P, I64, F, P, I64, F, P, P, c_int, P]),
     "hmx_linear_wgrad_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "hmx_linear_wgrad_f32": (c_int, [P, I64, P, I64, P, I64, I64, I64, P, I64, P, P, c_size_t, P]),
+    "hmx_linear_wgrad_batch_workspace_bytes": (c_size_t, [ctypes.POINTER(WgradDesc), I64]),
+    "hmx_linear_wgrad_batch_f32": (c_int, [ctypes.POINTER(WgradDesc), I64, P, c_size_t, P]),
     "hmx_silu_rope_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, P, P]),
     "hmx_silu_rope_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, P, P]),
     "hmx_binary_fwd": (c_int, [P, P, I64, F, c_int, P, P]),

@@ -72,8 +72,8 @@ class MambaBlock(nn.Module):
 def mamba_heads(blocks, s, L):
     """All heads' MambaBlocks at once.  s: (T, H*hd) -> (T, H*hd)."""
     ED, H = blocks[0].dim_inner, len(blocks)
-    x_in = E.heads_linear(s, [m.in_proj.weight[:ED] for m in blocks])
-    z = E.heads_linear(s, [m.in_proj.weight[ED:] for m in blocks])
+    x_in = E.heads_linear(s, [m.in_proj.weight for m in blocks], rows=(0, ED))
+    z = E.heads_linear(s, [m.in_proj.weight for m in blocks], rows=(ED, 2 * ED))
     one = H == 1
     cat = (lambda ts: ts[0]) if one else torch.cat
     xc = E.conv_silu(x_in, cat([m.conv1d.weight.view(ED, D_CONV) for m in blocks]),
@@ -360,6 +360,10 @@ class Hydra(nn.Module):
         self.position_aware_encoder = PositionAwareEncoder(d, max_len=args.maxlen + 1)
         self.enchanced_loss = EnhancedTrainingLoss(args)
         self._prepared = None
+        # direct-gradient mode (enc_ops.set_direct_param_grad): the small parameters' .grad tensors are views of one
+        # flat buffer; the two big tables keep their own dense gradients
+        se = self.shared_embeddings
+        E.register_grad_arena(self, exclude=(se.item_emb.weight, se.user_emb.weight))
 
     # ---- input assembly (hydra3.py:621-669) --------------------------------------------------
     def _project_small(self, rows):

@@ -209,11 +209,32 @@ int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, in
                    int accumulate, void* stream);
 
 /* Weight / bias gradient on fp32 MFMA: dW[n * ldw + k] = sum_t dY[t, n] * X[t, k] * in_rowmask[t],
- * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  Deterministic two-stage reduction over tokens. */
+ * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  One launch: token splits write partial tiles to the workspace and
+ * the workgroup that finishes a tile last adds them in split order (deterministic, no float atomics).  The arrival
+ * counters of that hand-over live inside the library (zero between launches); up to sixteen launches may be in
+ * flight at once on different streams. */
+typedef struct hmx_wgrad_desc {
+    const float* dY;          /* (T, N) with row stride ldy                                   */
+    int64_t ldy;
+    const float* X;           /* (T, K) with row stride ldx                                   */
+    int64_t ldx;
+    const float* in_rowmask;  /* (T) or NULL                                                  */
+    int64_t T, N, K;
+    float* dW;                /* (N, K) with row stride ldw                                   */
+    int64_t ldw;
+    float* dbias;             /* (N) or NULL                                                  */
+    int32_t accumulate;       /* 0: dW / dbias are overwritten; 1: the result is added to them */
+} hmx_wgrad_desc;
 size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K);
 int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, const float* in_rowmask, int64_t T,
                          int64_t N, int64_t K, float* dW, int64_t ldw, float* dbias, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* Up to 24 weight-gradient products in ONE launch (descs is a host array, read before the call returns).  The
+ * backward pass of an encoder block has some thirty of these products, each a few microseconds of work: batched,
+ * they fill the chip once instead of thirty times.  No two descriptors of a call may write the same dW / dbias. */
+size_t hmx_linear_wgrad_batch_workspace_bytes(const hmx_wgrad_desc* descs, int64_t n);
+int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* s = SiLU(x1); y2 = RoPE(s) on interleaved pairs per head, position = t mod L, angle tables cos/sin of
  * shape (L, hd/2) (hydra3.py:300-357, 368, 381-386).  Backward: dx1 = (ds + RoPE^T(dy2)) * SiLU'(x1). */

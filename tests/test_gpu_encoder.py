@@ -242,6 +242,41 @@ def test_fused_table_gradients_are_bit_identical_to_autograd_accumulation():
             assert torch.equal(a, c), k
 
 
+def test_direct_parameter_gradients_match_autograd_accumulation():
+    """enc_ops.set_direct_param_grad(True): the projections' weight gradients are queued and computed by batched
+    launches that add straight into .grad (views of one flat buffer).  Against the one-launch-per-product autograd
+    path on the same step: same parameters get a gradient, values agree to fp32 rounding (the batched launch splits
+    the token range differently, so the association order differs), parameters without a gradient stay None."""
+    from generative_recommenders_amd import ops
+    s, p = G.load("g10_train"), "G10_train_chunky"
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    hard, inb = G.assemble_train_draws(s, p, G.t(s, p + "/next_tok") == 1)
+    grads, losses = [], []
+    try:
+        for direct in (False, True):
+            E.set_direct_param_grad(direct)
+            ops.set_fused_table_grad(direct)
+            m = _model_from(s, p, dropout=0.0).train()
+            for rep in range(2 if direct else 1):        # second pass: gradient buffers are recycled after zero_grad
+                m.zero_grad(set_to_none=True)
+                loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, feat, feat, feat, b["ts"], b["act"],
+                         b["dwell"], predrawn=(hard.to(DEV), inb.to(DEV)))
+                loss.backward()
+            losses.append(loss.item())
+            grads.append({k: (None if q.grad is None else q.grad.clone()) for k, q in m.named_parameters()})
+    finally:
+        E.set_direct_param_grad(False)
+        ops.set_fused_table_grad(False)
+    assert losses[0] == losses[1]
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        a, c = grads[0][k], grads[1][k]
+        assert (a is None) == (c is None), k
+        if a is not None:
+            close(c, a, 2e-5, 2e-5, "direct grad " + k)
+
+
 def test_log2feats_and_grads_vs_oracle_benchmark_shape():
     """d = 64, L = 100 (the benchmark model), B = 6 with ragged left padding; eval mode."""
     from generative_recommenders_amd import synth
