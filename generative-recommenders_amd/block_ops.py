@@ -1,0 +1,222 @@
+"""torch.autograd wrappers of the fused block halves of libhmx.so (hmx_block_*).
+
+A Hydra block (hydra3.py:392-457) runs as   pre half -> conv / deltaBC / scan (enc_ops) -> post half.
+The two halves are one kernel each per direction; see include/hmx.h for what each covers.  CUDA fp32 only.
+"""
+import ctypes
+
+import torch
+
+from . import enc_ops as E
+from . import hmx
+from .ops import _f32c, workspace
+
+
+def supported(d, n_heads):
+    return bool(hmx.lib().hmx_block_supported(d, n_heads))
+
+
+class PackedBlock:
+    """bf16 hi / lo fragment images of a block's projection weights (both orientations), packed by one launch.
+    Valid for the weights' current values: built once per forward pass and reused by that pass's backward."""
+
+    def __init__(self, blk):
+        mhm = blk.multiheadMamba
+        heads = list(mhm.mamba)
+        self.d = mhm.linear_layer1.weight.shape[0]
+        self.H = len(heads)
+        w = hmx.BlockWeights()
+        keep = []
+        for name, q in (("W1", mhm.linear_layer1.weight), ("W2", mhm.linear_layer2.weight), ("Wg", blk.gate.weight),
+                        ("Wu", blk.up.weight), ("Wd", blk.down.weight)):
+            t = _f32c(q.detach())
+            keep.append(t)
+            setattr(w, name, t.data_ptr())
+        for h, m in enumerate(heads):
+            a, b = _f32c(m.in_proj.weight.detach()), _f32c(m.out_proj.weight.detach())
+            keep += [a, b]
+            w.Win[h], w.Wout[h] = a.data_ptr(), b.data_ptr()
+        L = hmx.lib()
+        dev = keep[0].device
+        self.buf = torch.empty(L.hmx_block_packed_bytes(self.d, self.H), dtype=torch.uint8, device=dev)
+        hmx.check(L.hmx_block_pack_f32(ctypes.byref(w), self.d, self.H, hmx.ptr(self.buf), hmx.current_stream()),
+                  "hmx_block_pack_f32")
+
+
+def _args(T, L, d, H, first, eps, packed, **ptrs):
+    a = hmx.BlockArgs()
+    a.T, a.L, a.d, a.H, a.first, a.eps = T, L, d, H, int(first), eps
+    a.packed = packed.buf.data_ptr()
+    for k, v in ptrs.items():
+        setattr(a, k, None if v is None else v.data_ptr())
+    return a
+
+
+def _scale_grad(part):
+    return E.colsum(part)
+
+
+def _weight_grads(jobs, params, device):
+    """jobs: (param index, dy, dy_off, ldy, x, x_off, ldx, in_mask, T, N, K, dw_off, ldw, bias param index or None).
+    Direct-gradient mode queues them (added into .grad by the batched launch); otherwise one batched launch writes
+    fresh gradient tensors, returned by position (None where the mode handled it or no gradient is needed)."""
+    grads = [None] * len(params)
+    immediate, descs, keep = [], [], []
+    for (pi, dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, dw_off, ldw, bi) in jobs:
+        q = params[pi]
+        if q is None or not q.requires_grad:
+            continue
+        bq = params[bi] if bi is not None else None
+        want_b = bq is not None and bq.requires_grad
+        tw = E._param_grad_target(q)
+        tb = E._param_grad_target(bq) if want_b else None
+        if tw is not None and (tb is not None or not want_b):
+            E._wgrad_queue.add(dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, tw, dw_off, ldw, tb, 0)
+            continue
+        if grads[pi] is None:
+            grads[pi] = torch.zeros_like(q, memory_format=torch.contiguous_format)
+        if want_b and grads[bi] is None:
+            grads[bi] = torch.zeros_like(bq)
+        immediate.append((dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, grads[pi], dw_off, ldw, grads[bi] if want_b else None))
+    if immediate:
+        for (dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, dw, dw_off, ldw, db) in immediate:
+            descs.append(hmx.WgradDesc(dy.data_ptr() + 4 * dy_off, ldy, x.data_ptr() + 4 * x_off, ldx,
+                                       mask.data_ptr() if mask is not None else None, T, N, K,
+                                       dw.data_ptr() + 4 * dw_off, ldw, db.data_ptr() if db is not None else None, 1))
+        for i in range(0, len(descs), 24):
+            chunk = descs[i:i + 24]
+            arr = (hmx.WgradDesc * len(chunk))(*chunk)
+            lib = hmx.lib()
+            ws = workspace(lib.hmx_linear_wgrad_batch_workspace_bytes(arr, len(chunk)), device)
+            hmx.check(lib.hmx_linear_wgrad_batch_f32(arr, len(chunk), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
+                      "hmx_linear_wgrad_batch_f32")
+    return grads
+
+
+class _Link:
+    """Carries dm (the gradient of the RMSNorm2 input) from the post half's backward to the pre half's backward,
+    which owns both residual paths of the block input (x itself, and in the first block the normalised n)."""
+    dm = None
+
+
+class _BlockPre(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, drop, mask, packed, link, L, H, first, eps, scale1, W1, b1, *Win):
+        x = _f32c(x)
+        T, d = x.shape
+        C = 4 * d
+        cos, sin = E.rope_tables(L, d // H, x.device)
+        mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=x.device)   # noqa: E731
+        rstd1, x_in, z, y2 = mk(T), mk(T, C), mk(T, C), mk(T, d)
+        sc, b = _f32c(scale1.detach()), _f32c(b1.detach())
+        a = _args(T, L, d, H, first, eps, packed, mask=mask, x=x, drop=drop, scale1=sc, b1=b, rope_cos=cos, rope_sin=sin,
+                  rstd1=rstd1, x_in=x_in, z=z, y2=y2)
+        hmx.check(hmx.lib().hmx_block_pre_fwd(ctypes.byref(a), hmx.current_stream()), "hmx_block_pre_fwd")
+        ctx.save_for_backward(x, drop, mask, sc, b)
+        ctx.cfg = (L, H, first, eps, packed, link)
+        ctx.params = (scale1, W1, b1) + tuple(Win)
+        ctx.mark_non_differentiable(rstd1)
+        return x_in, z, y2, rstd1
+
+    @staticmethod
+    def backward(ctx, dx_in, dz, dy2, _):
+        x, drop, mask, sc, b = ctx.saved_tensors
+        L, H, first, eps, packed, link = ctx.cfg
+        T, d = x.shape
+        C, hd, ED = 4 * d, d // H, 4 * d // H
+        dev = x.device
+        mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
+        zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)   # noqa: E731
+        dx_in = _f32c(dx_in) if dx_in is not None else zeros(T, C)
+        dz = _f32c(dz) if dz is not None else zeros(T, C)
+        dy2 = _f32c(dy2) if dy2 is not None else zeros(T, d)
+        dm = link.dm if link.dm is not None else zeros(T, d)
+        link.dm = None
+        cos, sin = E.rope_tables(L, hd, dev)
+        rows = int(hmx.lib().hmx_block_scale_partial_rows(T))
+        dx, s, dx1, n, part = mk(T, d), mk(T, d), mk(T, d), mk(T, d), mk(rows, d)
+        a = _args(T, L, d, H, first, eps, packed, mask=mask, x=x, drop=drop, scale1=sc, b1=b, rope_cos=cos, rope_sin=sin,
+                  dx_in=dx_in, dz=dz, dy2=dy2, dm=dm, dx=dx, s=s, dx1=dx1, n=n, dscale_part=part)
+        hmx.check(hmx.lib().hmx_block_pre_bwd(ctypes.byref(a), hmx.current_stream()), "hmx_block_pre_bwd")
+        params = ctx.params            # (scale1, W1, b1, Win_0 ...)
+        jobs = [(1, dx1, 0, d, n, 0, d, mask, T, d, d, 0, d, 2)]
+        for h in range(H):
+            jobs.append((3 + h, dx_in, h * ED, C, s, h * hd, d, None, T, ED, hd, 0, hd, None))
+            jobs.append((3 + h, dz, h * ED, C, s, h * hd, d, None, T, ED, hd, ED * hd, hd, None))
+        g = _weight_grads(jobs, params, dev)
+        g[0] = _scale_grad(part) if params[0].requires_grad else None
+        return (dx, None, None, None, None, None, None, None, None) + tuple(g)
+
+
+class _BlockPost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, yg, y2, x, drop, rstd1, mask, packed, link, L, H, first, eps, scale1, scale2, W2, b2, Wg, Wu, Wd, *Wout):
+        yg, y2, x = _f32c(yg), _f32c(y2), _f32c(x)
+        T, d = x.shape
+        mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=x.device)   # noqa: E731
+        out, m, rstd2 = mk(T, d), mk(T, d), mk(T)
+        sc1, sc2, bb = _f32c(scale1.detach()), _f32c(scale2.detach()), _f32c(b2.detach())
+        a = _args(T, L, d, H, first, eps, packed, mask=mask, x=x, drop=drop, scale1=sc1, rstd1=rstd1, yg=yg, y2=y2, b2=bb,
+                  scale2=sc2, out=out, m=m, rstd2=rstd2)
+        hmx.check(hmx.lib().hmx_block_post_fwd(ctypes.byref(a), hmx.current_stream()), "hmx_block_post_fwd")
+        ctx.save_for_backward(yg, y2, mask, m, rstd2, sc2)
+        ctx.cfg = (L, H, first, eps, packed, link)
+        ctx.params = (scale2, W2, b2, Wg, Wu, Wd) + tuple(Wout)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        yg, y2, mask, m, rstd2, sc2 = ctx.saved_tensors
+        L, H, first, eps, packed, link = ctx.cfg
+        T, d = m.shape
+        C, hd, ED = 4 * d, d // H, 4 * d // H
+        dev = m.device
+        dout = _f32c(dout)
+        mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)   # noqa: E731
+        rows = int(hmx.lib().hmx_block_scale_partial_rows(T))
+        dyg, dy2, dm = mk(T, C), mk(T, d), mk(T, d)
+        hmid, n2, dg, du, pp, dy1, part = mk(T, d), mk(T, d), mk(T, d), mk(T, d), mk(T, d), mk(T, d), mk(rows, d)
+        a = _args(T, L, d, H, first, eps, packed, mask=mask, yg=yg, y2=y2, scale2=sc2, m=m, rstd2=rstd2, dout=dout,
+                  dyg=dyg, dy2=dy2, dm=dm, hmid=hmid, n2=n2, dg=dg, du=du, p=pp, dy1=dy1, dscale_part=part)
+        hmx.check(hmx.lib().hmx_block_post_bwd(ctypes.byref(a), hmx.current_stream()), "hmx_block_post_bwd")
+        link.dm = dm
+        params = ctx.params            # (scale2, W2, b2, Wg, Wu, Wd, Wout_0 ...)
+        jobs = [(1, dm, 0, d, pp, 0, d, None, T, d, d, 0, d, 2),
+                (3, dg, 0, d, n2, 0, d, None, T, d, d, 0, d, None),
+                (4, du, 0, d, n2, 0, d, None, T, d, d, 0, d, None),
+                (5, dout, 0, d, hmid, 0, d, mask, T, d, d, 0, d, None)]
+        for h in range(H):
+            jobs.append((6 + h, dy1, h * hd, d, yg, h * ED, C, None, T, hd, ED, 0, ED, None))
+        g = _weight_grads(jobs, params, dev)
+        g[0] = _scale_grad(part) if params[0].requires_grad else None
+        # x and (first block) n receive their share of dm in the pre half's backward
+        return (dyg, dy2, None, None, None, None, None, None, None, None, None, None, None) + tuple(g)
+
+
+def hydra_block(blk, x2, mask1, L, first):
+    """One HydraBlockFirst / HydraBlock on the fused halves.  x2 (T, d), mask1 (T) or None -> (T, d)."""
+    mhm = blk.multiheadMamba
+    heads = list(mhm.mamba)
+    H = len(heads)
+    T, d = x2.shape
+    ED = heads[0].dim_inner
+    packed = PackedBlock(blk)
+    link = _Link()
+    drop = None
+    pdrop = blk.dropout.p
+    if blk.training and pdrop > 0.0:
+        drop = torch.empty(T, d, dtype=torch.float32, device=x2.device).bernoulli_(1.0 - pdrop).mul_(1.0 / (1.0 - pdrop))
+    eps = blk.norm1.eps
+    x_in, z, y2, rstd1 = _BlockPre.apply(x2, drop, mask1, packed, link, L, H, first, eps, blk.norm1.scale,
+                                         mhm.linear_layer1.weight, mhm.linear_layer1.bias,
+                                         *[m.in_proj.weight for m in heads])
+    one = H == 1
+    cat = (lambda ts: ts[0]) if one else torch.cat
+    xc = E.conv_silu(x_in, cat([m.conv1d.weight.view(ED, 4) for m in heads]), cat([m.conv1d.bias for m in heads]), L)
+    dbc = E.heads_linear(xc, [m.ssm.deltaBC_layer.weight for m in heads])
+    yg = E.selective_scan_gated(xc, z, dbc, cat([m.ssm.dt_proj_layer.weight for m in heads]),
+                                cat([m.ssm.dt_proj_layer.bias for m in heads]), cat([m.ssm.A_log for m in heads]),
+                                cat([m.ssm.D for m in heads]), L, ED, H)
+    return _BlockPost.apply(yg, y2, x2, drop, rstd1, mask1, packed, link, L, H, first, blk.norm2.eps, blk.norm1.scale,
+                            blk.norm2.scale, mhm.linear_layer2.weight, mhm.linear_layer2.bias, blk.gate.weight,
+                            blk.up.weight, blk.down.weight, *[m.out_proj.weight for m in heads])

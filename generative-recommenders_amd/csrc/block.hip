@@ -1,0 +1,846 @@
+// Fused token-parallel halves of a Hydra block (hydra3.py:359-389, 410-457), forward and backward.
+//
+// A block is   x -> [dropout, RMSNorm1, linear1, SiLU, RoPE, in_proj]  ->  conv / deltaBC / scan (sequence kernels)
+//                -> [out_proj, y1*y2, linear2 + residuals, RMSNorm2, SwiGLU FFN + residual, mask]  -> out.
+// The two bracketed halves have no dependence between tokens, so each is ONE kernel here: a wave owns 32 tokens and
+// carries every intermediate in the accumulator layout of the 32x32 MFMA with FEATURES on the rows and TOKENS on the
+// columns (lane & 31 = token, the 16 registers x 2 lane halves = 32 features).  In that layout
+//   * a pointwise op (SiLU, RoPE pairs, gates, residuals) is lane-local,
+//   * a row statistic (RMSNorm) is a sum over a lane's registers plus ONE exchange with lane ^ 32,
+//   * a tile is already the B operand of the next product (k order permuted; the weights are packed to match),
+// so no intermediate goes through LDS or HBM.  Weights arrive pre-packed (hmx_block_pack_f32) as bf16 hi / lo
+// fragment pairs in exactly the order a lane consumes them: the A operand of an MFMA is one 16-byte load per lane from
+// L2.  Products are split-bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate): fp32-class accuracy at three MFMAs.
+//
+// Backward kernels recompute the cheap intermediates from what the forward pass saved (x, rstd, the pre-norm sum m,
+// the scan output) and write the operand pairs of every weight gradient for the batched weight-gradient launch.
+#include <algorithm>
+
+#include "hmx_common.h"
+
+#pragma clang fp contract(fast)
+
+namespace {
+
+using short8 = __attribute__((ext_vector_type(8))) short;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float sigmoid_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_(float x) { return x * sigmoid_(x); }
+__device__ __forceinline__ float silu_grad_(float x) {
+    const float s = sigmoid_(x);
+    return s * (1.f + x * (1.f - s));
+}
+
+struct Frag {
+    short8 hi, lo;
+};
+
+// eight fp32 values -> bf16 hi / lo fragment (x = hi + lo to 16 significant bits)
+__device__ __forceinline__ Frag make_frag(const float (&v)[8]) {
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hw[e] = hmx_pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        lw[e] = hmx_pack_bf16x2(v[2 * e] - __uint_as_float(hw[e] << 16), v[2 * e + 1] - __uint_as_float(hw[e] & 0xffff0000u));
+    }
+    Frag f;
+    f.hi = __builtin_bit_cast(short8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+    f.lo = __builtin_bit_cast(short8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+    return f;
+}
+
+// Accumulator tile (32 features x 32 tokens) -> the B fragments of its two k-steps.  Register 8 s + j of lane half h is
+// feature 16 s + 8 (j >> 2) + 4 h + (j & 3) of the tile: the k order the packed weights use.
+__device__ __forceinline__ void tile_frags(const f32x16& a, Frag& f0, Frag& f1) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a[j];
+    f0 = make_frag(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a[8 + j];
+    f1 = make_frag(v);
+}
+
+// B fragment of k-step ks straight from a row-major fp32 row: columns 16 ks + 4 h + (0..3) and + 8
+__device__ __forceinline__ Frag row_frag(const float* row, int ks, int h) {
+    const float4 a = *reinterpret_cast<const float4*>(row + 16 * ks + 4 * h);
+    const float4 b = *reinterpret_cast<const float4*>(row + 16 * ks + 8 + 4 * h);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return make_frag(v);
+}
+
+// acc += W(tile nt, k-step ks) * B   with W packed as [(nt * KS + ks) * 2 + part][lane] 16-byte entries
+__device__ __forceinline__ void mma(f32x16& acc, const uint4* pk, int nt, int KS, int ks, const Frag& b, int lane) {
+    const uint4* e = pk + ((size_t)(nt * KS + ks) * 2) * 64 + lane;
+    const short8 a_hi = __builtin_bit_cast(short8, e[0]);
+    const short8 a_lo = __builtin_bit_cast(short8, e[64]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.hi, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void zero(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// Tile nt of a row-major (.., ld) fp32 row in accumulator layout: register 4 q + e <-> column 32 nt + 8 q + 4 h + e
+__device__ __forceinline__ void load_tile(f32x16& a, const float* row, int nt, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 32 * nt + 8 * q + 4 * h);
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void store_tile(const f32x16& a, float* row, int nt, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(row + 32 * nt + 8 * q + 4 * h) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+
+// sum of a per-lane value over the two lanes (l, l ^ 32) that share a token
+__device__ __forceinline__ float pair_sum(float v) { return v + __shfl_xor(v, 32); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Packed weights of one block.  All offsets in 16-byte entries.  "T" = the transposed product of the backward pass.
+struct PackLayout {
+    int d, H, hd, ED, NT, NTh, KSd, KSh, KSe, KSz;
+    // forward: W1, W2, Wg, Wu, Wd (d x d), Win[h] (2 ED x hd), Wout[h] (hd x ED)
+    size_t w1, w2, wg, wu, wd, win, wout, win_stride, wout_stride;
+    // transposed: W1T .. WdT (d x d), WinT[h] (hd x 2 ED), WoutT[h] (ED x hd)
+    size_t w1t, w2t, wgt, wut, wdt, wint, woutt, wint_stride, woutt_stride;
+    size_t total;
+};
+
+__host__ __device__ inline size_t pack_entries(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 2 * 64; }
+
+__host__ __device__ inline PackLayout make_layout(int d, int H) {
+    PackLayout l{};
+    l.d = d; l.H = H; l.hd = d / H; l.ED = 4 * l.hd;
+    l.NT = d / 32; l.NTh = l.hd / 32; l.KSd = d / 16; l.KSh = l.hd / 16; l.KSe = l.ED / 16; l.KSz = 2 * l.ED / 16;
+    size_t o = 0;
+    const size_t dd = pack_entries(d, d);
+    l.w1 = o; o += dd; l.w2 = o; o += dd; l.wg = o; o += dd; l.wu = o; o += dd; l.wd = o; o += dd;
+    l.win_stride = pack_entries(2 * l.ED, l.hd); l.win = o; o += l.win_stride * H;
+    l.wout_stride = pack_entries(l.hd, l.ED); l.wout = o; o += l.wout_stride * H;
+    l.w1t = o; o += dd; l.w2t = o; o += dd; l.wgt = o; o += dd; l.wut = o; o += dd; l.wdt = o; o += dd;
+    l.wint_stride = pack_entries(l.hd, 2 * l.ED); l.wint = o; o += l.wint_stride * H;
+    l.woutt_stride = pack_entries(l.ED, l.hd); l.woutt = o; o += l.woutt_stride * H;
+    l.total = o;
+    return l;
+}
+
+struct PackJob {
+    const float* W;
+    int64_t rs, cs;     // Wv(n, k) = W[n * rs + k * cs]
+    int N, K;
+    size_t out;         // entry offset
+};
+constexpr int kMaxPackJobs = 2 * (5 + 2 * 8);
+struct PackParams {
+    PackJob job[kMaxPackJobs];
+    int n_jobs;
+    uint4* out;
+};
+
+// entry (nt, ks, part, lane): element j = Wv(32 nt + (lane & 31), 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3))
+__global__ __launch_bounds__(256) void block_pack_kernel(PackParams p) {
+    const PackJob& jb = p.job[blockIdx.y];
+    const int KS = (jb.K + 15) / 16, NTo = (jb.N + 31) / 32;
+    const int n_frag = NTo * KS * 64;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n_frag; idx += gridDim.x * 256) {
+        const int lane = idx & 63, ks = (idx >> 6) % KS, nt = (idx >> 6) / KS;
+        const int n = 32 * nt + (lane & 31), h = lane >> 5;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+            v[j] = (n < jb.N && k < jb.K) ? jb.W[(int64_t)n * jb.rs + (int64_t)k * jb.cs] : 0.f;
+        }
+        const Frag f = make_frag(v);
+        uint4* e = p.out + jb.out + ((size_t)(nt * KS + ks) * 2) * 64 + lane;
+        e[0] = __builtin_bit_cast(uint4, f.hi);
+        e[64] = __builtin_bit_cast(uint4, f.lo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct BlockParams {
+    int64_t T;
+    int L, first;
+    float eps, inv_sqrt_h;
+    PackLayout lay;
+    const uint4* pk;
+    const float* mask;      // (T)
+    // pre half
+    const float* x;         // (T, d) block input
+    const float* drop;      // (T, d) dropout multiplier or null
+    const float* scale1;    // (d)
+    const float* b1;        // (d)
+    const float* cs;        // rope cos (L, hd / 2)
+    const float* sn;        // rope sin
+    float* rstd1;           // (T)
+    float* x_in;            // (T, C)
+    float* z;               // (T, C)
+    float* y2;              // (T, d)
+    // post half
+    const float* yg;        // (T, C)
+    const float* b2;        // (d)
+    const float* scale2;    // (d)
+    float* out;             // (T, d)
+    float* m;               // (T, d)  x_org + W2 p + b2 + residual (input of RMSNorm2)
+    float* rstd2;           // (T)
+    // backward, post half
+    const float* dout;      // (T, d)
+    float* dyg;             // (T, C)
+    float* dy2;             // (T, d)
+    float* dm;              // (T, d)
+    float* hmid;            // (T, d)   wgrad operands
+    float* n2;
+    float* dg;
+    float* du;
+    float* p;
+    float* dy1;
+    float* dscale_part;     // (waves, d)
+    // backward, pre half
+    const float* dx_in;     // (T, C)
+    const float* dz;        // (T, C)
+    float* dx;              // (T, d)
+    float* s;               // (T, d)   wgrad operands
+    float* dx1;
+    float* n;
+};
+
+constexpr int kMaxNT = 4;   // d <= 128
+
+// dropout multiplier, RMSNorm1: fills xd (x * drop), returns rstd; n = xd * rstd * scale1
+template <int NT>
+__device__ __forceinline__ float norm1(const BlockParams& p, const float* xrow, const float* droprow, int h,
+                                       f32x16 (&xd)[NT], f32x16 (&n)[NT]) {
+    float ss = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        load_tile(xd[nt], xrow, nt, h);
+        if (droprow != nullptr) {
+            f32x16 dr;
+            load_tile(dr, droprow, nt, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xd[nt][r] *= dr[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ss += xd[nt][r] * xd[nt][r];
+    }
+    ss = pair_sum(ss);
+    const float rstd = 1.f / sqrtf(ss / (float)(32 * NT) + p.eps);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x16 sc;
+        load_tile(sc, p.scale1, nt, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) n[nt][r] = xd[nt][r] * rstd * sc[r];
+    }
+    return rstd;
+}
+
+// x1 = W1 (n * mask) + b1
+template <int NT>
+__device__ __forceinline__ void linear1(const BlockParams& p, const f32x16 (&n)[NT], float mk, int h, int lane, f32x16 (&x1)[NT]) {
+    Frag nf[2 * NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x16 t = n[nt];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] *= mk;
+        tile_frags(t, nf[2 * nt], nf[2 * nt + 1]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        load_tile(x1[nt], p.b1, nt, h);
+#pragma unroll
+        for (int ks = 0; ks < 2 * NT; ++ks) mma(x1[nt], p.pk + p.lay.w1, nt, 2 * NT, ks, nf[ks], lane);
+    }
+}
+
+// ------------------------------------------------------------------ pre half, forward
+template <int NT>
+__global__ __launch_bounds__(256) void block_pre_fwd_kernel(BlockParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const PackLayout& l = p.lay;
+    const int d = 32 * NT, C = l.H * l.ED;
+    const int64_t n_tiles = hmx_ceil_div(p.T, 32);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t t = tile * 32 + i;
+        const bool ok = t < p.T;
+        const int64_t tt = ok ? t : p.T - 1;
+        f32x16 xd[NT], n[NT], x1[NT];
+        const float rstd = norm1<NT>(p, p.x + tt * d, p.drop ? p.drop + tt * d : nullptr, h, xd, n);
+        linear1<NT>(p, n, p.mask ? p.mask[tt] : 1.f, h, lane, x1);
+        // s = SiLU(x1) (kept in x1), y2 = RoPE(s): pairs (2 i, 2 i + 1) are registers (e, e + 1), e even
+        const int pos = (int)(tt % p.L);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 y2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 32 * nt + 8 * q + 4 * h;                   // first feature of this register quad
+                const int ip = (f0 % l.hd) / 2;
+                const float2 c = *reinterpret_cast<const float2*>(p.cs + pos * (l.hd / 2) + ip);
+                const float2 sv = *reinterpret_cast<const float2*>(p.sn + pos * (l.hd / 2) + ip);
+                const float s0 = silu_(x1[nt][4 * q]), s1 = silu_(x1[nt][4 * q + 1]);
+                const float s2 = silu_(x1[nt][4 * q + 2]), s3 = silu_(x1[nt][4 * q + 3]);
+                x1[nt][4 * q] = s0; x1[nt][4 * q + 1] = s1; x1[nt][4 * q + 2] = s2; x1[nt][4 * q + 3] = s3;
+                y2[4 * q] = s0 * c.x - s1 * sv.x;
+                y2[4 * q + 1] = s0 * sv.x + s1 * c.x;
+                y2[4 * q + 2] = s2 * c.y - s3 * sv.y;
+                y2[4 * q + 3] = s2 * sv.y + s3 * c.y;
+            }
+            if (ok) store_tile(y2, p.y2 + t * d, nt, h);
+        }
+        // in_proj per head: [x_in | z] = Win_h s_h, streamed one 32-channel output tile at a time
+        Frag sf[2 * NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) tile_frags(x1[nt], sf[2 * nt], sf[2 * nt + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int hh = 0; hh < l.H; ++hh) {
+            const uint4* w = p.pk + l.win + hh * l.win_stride;
+#pragma unroll 1
+            for (int ot = 0; ot < 2 * l.ED / 32; ++ot) {
+                f32x16 acc;
+                zero(acc);
+#pragma unroll
+                for (int ks = 0; ks < 2 * NT; ++ks)
+                    if (ks >= hh * l.KSh && ks < (hh + 1) * l.KSh) mma(acc, w, ot, l.KSh, ks - hh * l.KSh, sf[ks], lane);
+                if (ok) {
+                    const int ch = ot * 32;
+                    float* dst = (ch < l.ED ? p.x_in : p.z) + t * C + hh * l.ED + (ch < l.ED ? ch : ch - l.ED);
+                    store_tile(acc, dst, 0, h);
+                }
+            }
+        }
+        if (ok && h == 0) p.rstd1[t] = rstd;
+    }
+}
+
+// ------------------------------------------------------------------ post half, forward
+// y1 = Wout_h yg_h for every head (feature tiles of head h: [h * NTh, (h + 1) * NTh))
+template <int NT>
+__device__ __forceinline__ void out_proj(const BlockParams& p, const float* ygrow, int h, int lane, f32x16 (&y1)[NT]) {
+    const PackLayout& l = p.lay;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) zero(y1[nt]);
+#pragma unroll 1
+    for (int hh = 0; hh < l.H; ++hh) {
+        const uint4* w = p.pk + l.wout + hh * l.wout_stride;
+
+        for (int ks = 0; ks < l.KSe; ++ks) {
+            const Frag f = row_frag(ygrow + hh * l.ED, ks, h);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh) mma(y1[nt], w, nt - hh * l.NTh, l.KSe, ks, f, lane);
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void block_post_fwd_kernel(BlockParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const PackLayout& l = p.lay;
+    const int d = 32 * NT, C = l.H * l.ED;
+    const int64_t n_tiles = hmx_ceil_div(p.T, 32);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t t = tile * 32 + i;
+        const bool ok = t < p.T;
+        const int64_t tt = ok ? t : p.T - 1;
+        f32x16 m[NT];
+        {
+            f32x16 y1[NT];
+            out_proj<NT>(p, p.yg + tt * C, h, lane, y1);
+            Frag pf[2 * NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {      // p = y1 * y2 / sqrt(H)
+                f32x16 y2;
+                load_tile(y2, p.y2 + tt * d, nt, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y1[nt][r] *= y2[r] * p.inv_sqrt_h;
+                tile_frags(y1[nt], pf[2 * nt], pf[2 * nt + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // m = W2 p + b2 + x_org + (first ? n : x)
+            const float rstd1 = p.first ? p.rstd1[tt] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                load_tile(m[nt], p.b2, nt, h);
+#pragma unroll
+                for (int ks = 0; ks < 2 * NT; ++ks) mma(m[nt], p.pk + l.w2, nt, 2 * NT, ks, pf[ks], lane);
+                f32x16 xv;
+                load_tile(xv, p.x + tt * d, nt, h);
+                if (p.first) {
+                    f32x16 sc;
+                    load_tile(sc, p.scale1, nt, h);
+                    if (p.drop != nullptr) {
+                        f32x16 dr;
+                        load_tile(dr, p.drop + tt * d, nt, h);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) m[nt][r] += xv[r] + xv[r] * dr[r] * rstd1 * sc[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) m[nt][r] += xv[r] + xv[r] * rstd1 * sc[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[nt][r] += 2.f * xv[r];
+                }
+                if (ok) store_tile(m[nt], p.m + t * d, nt, h);
+            }
+        }
+        // RMSNorm2
+        float ss = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ss += m[nt][r] * m[nt][r];
+        ss = pair_sum(ss);
+        const float rstd2 = 1.f / sqrtf(ss / (float)d + p.eps);
+        f32x16 n2[NT];
+        Frag nf[2 * NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 sc;
+            load_tile(sc, p.scale2, nt, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) n2[nt][r] = m[nt][r] * rstd2 * sc[r];
+            tile_frags(n2[nt], nf[2 * nt], nf[2 * nt + 1]);
+        }
+        // out = Wd (SiLU(Wg n2) * (Wu n2)) + (first ? n2 : m), streamed over the hidden tiles
+        f32x16 o[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = p.first ? n2[nt] : m[nt];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int ht = 0; ht < NT; ++ht) {       // a real loop: bounds how far the compiler hoists the weight loads
+            f32x16 g, u;
+            zero(g);
+            zero(u);
+#pragma unroll
+            for (int ks = 0; ks < 2 * NT; ++ks) {
+                mma(g, p.pk + l.wg, ht, 2 * NT, ks, nf[ks], lane);
+                mma(u, p.pk + l.wu, ht, 2 * NT, ks, nf[ks], lane);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = silu_(g[r]) * u[r];
+            Frag h0, h1;
+            tile_frags(g, h0, h1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                mma(o[nt], p.pk + l.wd, nt, 2 * NT, 2 * ht, h0, lane);
+                mma(o[nt], p.pk + l.wd, nt, 2 * NT, 2 * ht + 1, h1, lane);
+            }
+        }
+        if (ok) {
+            const float mk = p.mask ? p.mask[t] : 1.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[nt][r] *= mk;
+                store_tile(o[nt], p.out + t * d, nt, h);
+            }
+            if (h == 0) p.rstd2[t] = rstd2;
+        }
+    }
+}
+
+// Column sums over a wave's tokens of per-lane partials held in accumulator layout -> one row of (waves, d).
+template <int NT>
+__device__ __forceinline__ void write_scale_partial(const f32x16 (&acc)[NT], float* part_row, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[nt][r];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);     // over the 32 token lanes of a half
+            if ((lane & 31) == 0) part_row[32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h] = v;
+        }
+}
+
+// ------------------------------------------------------------------ post half, backward
+template <int NT>
+__global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const PackLayout& l = p.lay;
+    const int d = 32 * NT, C = l.H * l.ED;
+    const int64_t n_tiles = hmx_ceil_div(p.T, 32);
+    f32x16 dsc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) zero(dsc[nt]);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t t = tile * 32 + i;
+        const bool ok = t < p.T;
+        const int64_t tt = ok ? t : p.T - 1;
+        const float mk = (p.mask ? p.mask[tt] : 1.f) * (ok ? 1.f : 0.f);
+        const float rstd2 = p.rstd2[tt];
+        // Only fragments stay live across a phase; m, scale2 and dout are re-read (L1 / L2 hits) where a later phase
+        // needs them again: the register file holds the fragments, the accumulators and one phase's temporaries.
+        Frag nf[2 * NT], dof[2 * NT];
+        f32x16 dn2[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 mt, sc, n2, dot_;
+            load_tile(mt, p.m + tt * d, nt, h);
+            load_tile(sc, p.scale2, nt, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) n2[r] = mt[r] * rstd2 * sc[r];
+            tile_frags(n2, nf[2 * nt], nf[2 * nt + 1]);
+            if (ok) store_tile(n2, p.n2 + t * d, nt, h);
+            load_tile(dot_, p.dout + tt * d, nt, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot_[r] *= mk;                     // do = dout * mask
+            tile_frags(dot_, dof[2 * nt], dof[2 * nt + 1]);
+            if (p.first) dn2[nt] = dot_;                                   // out = f + n2
+            else zero(dn2[nt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // FFN backward, streamed over the hidden tiles: recompute g, u; dhmid = Wd^T do; dn2 += Wg^T dg + Wu^T du
+#pragma unroll 1
+        for (int ht = 0; ht < NT; ++ht) {
+            f32x16 g, u, dh;
+            zero(g);
+            zero(u);
+            zero(dh);
+#pragma unroll
+            for (int ks = 0; ks < 2 * NT; ++ks) {
+                mma(g, p.pk + l.wg, ht, 2 * NT, ks, nf[ks], lane);
+                mma(u, p.pk + l.wu, ht, 2 * NT, ks, nf[ks], lane);
+                mma(dh, p.pk + l.wdt, ht, 2 * NT, ks, dof[ks], lane);
+            }
+            f32x16 hm, dg, du;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sg = silu_(g[r]);
+                hm[r] = sg * u[r];
+                dg[r] = dh[r] * u[r] * silu_grad_(g[r]);
+                du[r] = dh[r] * sg;
+            }
+            if (ok) {
+                store_tile(hm, p.hmid + t * d, ht, h);
+                store_tile(dg, p.dg + t * d, ht, h);
+                store_tile(du, p.du + t * d, ht, h);
+            }
+            Frag g0, g1, u0, u1;
+            tile_frags(dg, g0, g1);
+            tile_frags(du, u0, u1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                mma(dn2[nt], p.pk + l.wgt, nt, 2 * NT, 2 * ht, g0, lane);
+                mma(dn2[nt], p.pk + l.wgt, nt, 2 * NT, 2 * ht + 1, g1, lane);
+                mma(dn2[nt], p.pk + l.wut, nt, 2 * NT, 2 * ht, u0, lane);
+                mma(dn2[nt], p.pk + l.wut, nt, 2 * NT, 2 * ht + 1, u1, lane);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // RMSNorm2 backward: dm = rstd (s dn2 - m rstd^2 mean(dn2 s m)) (+ do in a regular block: out = f + m)
+        float dot = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 mt, sc;
+            load_tile(mt, p.m + tt * d, nt, h);
+            load_tile(sc, p.scale2, nt, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot += dn2[nt][r] * sc[r] * mt[r];
+        }
+        dot = pair_sum(dot);
+        const float coef = dot * rstd2 * rstd2 / (float)d;
+        Frag dmf[2 * NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 mt, sc, dm;
+            load_tile(mt, p.m + tt * d, nt, h);
+            load_tile(sc, p.scale2, nt, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dsc[nt][r] += dn2[nt][r] * mt[r] * rstd2;                   // masked / padded tokens contribute dn2 = 0
+                dm[r] = rstd2 * (sc[r] * dn2[nt][r] - mt[r] * coef);
+            }
+            if (!p.first) {
+                f32x16 dot_;
+                load_tile(dot_, p.dout + tt * d, nt, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dm[r] += dot_[r] * mk;
+            }
+            if (ok) store_tile(dm, p.dm + t * d, nt, h);
+            tile_frags(dm, dmf[2 * nt], dmf[2 * nt + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // mixer tail backward: dp = W2^T dm; recompute y1; dy1 = dp y2 / sqrt(H), dy2 = dp y1 / sqrt(H); dyg = Wout^T dy1
+        f32x16 y1[NT];
+        out_proj<NT>(p, p.yg + tt * C, h, lane, y1);
+        Frag d1f[2 * NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 dp, y2;
+            zero(dp);
+#pragma unroll
+            for (int ks = 0; ks < 2 * NT; ++ks) mma(dp, p.pk + l.w2t, nt, 2 * NT, ks, dmf[ks], lane);
+            load_tile(y2, p.y2 + tt * d, nt, h);
+            f32x16 dy1, dy2, pp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pp[r] = y1[nt][r] * y2[r] * p.inv_sqrt_h;
+                dy1[r] = dp[r] * y2[r] * p.inv_sqrt_h;
+                dy2[r] = dp[r] * y1[nt][r] * p.inv_sqrt_h;
+            }
+            if (ok) {
+                store_tile(pp, p.p + t * d, nt, h);
+                store_tile(dy1, p.dy1 + t * d, nt, h);
+                store_tile(dy2, p.dy2 + t * d, nt, h);
+            }
+            tile_frags(dy1, d1f[2 * nt], d1f[2 * nt + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int hh = 0; hh < l.H; ++hh) {
+            const uint4* w = p.pk + l.woutt + hh * l.woutt_stride;
+#pragma unroll 1
+            for (int ot = 0; ot < l.ED / 32; ++ot) {
+                f32x16 acc;
+                zero(acc);
+#pragma unroll
+                for (int ks = 0; ks < 2 * NT; ++ks)
+                    if (ks >= hh * l.KSh && ks < (hh + 1) * l.KSh) mma(acc, w, ot, l.KSh, ks - hh * l.KSh, d1f[ks], lane);
+                if (ok) store_tile(acc, p.dyg + t * C + hh * l.ED + ot * 32, 0, h);
+            }
+        }
+    }
+    write_scale_partial<NT>(dsc, p.dscale_part + ((int64_t)blockIdx.x * 4 + wave) * d, lane);
+}
+
+// ------------------------------------------------------------------ pre half, backward
+template <int NT>
+__global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const PackLayout& l = p.lay;
+    const int d = 32 * NT, C = l.H * l.ED;
+    const int64_t n_tiles = hmx_ceil_div(p.T, 32);
+    f32x16 dsc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) zero(dsc[nt]);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t t = tile * 32 + i;
+        const bool ok = t < p.T;
+        const int64_t tt = ok ? t : p.T - 1;
+        const float live = ok ? 1.f : 0.f;
+        const float mk = p.mask ? p.mask[tt] : 1.f;
+        f32x16 xd[NT], n[NT], x1[NT];
+        const float rstd = norm1<NT>(p, p.x + tt * d, p.drop ? p.drop + tt * d : nullptr, h, xd, n);
+        linear1<NT>(p, n, mk, h, lane, x1);
+        // ds = sum_heads Win_h^T [dx_in_h ; dz_h]
+        f32x16 ds[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) zero(ds[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int hh = 0; hh < l.H; ++hh) {
+            const uint4* w = p.pk + l.wint + hh * l.wint_stride;
+
+            for (int ks = 0; ks < l.KSz; ++ks) {
+                const float* src = (ks < l.KSe ? p.dx_in : p.dz) + tt * C + hh * l.ED;
+                const Frag f = row_frag(src, ks < l.KSe ? ks : ks - l.KSe, h);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh) mma(ds[nt], w, nt - hh * l.NTh, l.KSz, ks, f, lane);
+            }
+        }
+        // + RoPE^T(dy2);  dx1 = ds * SiLU'(x1);  s = SiLU(x1)
+        const int pos = (int)(tt % p.L);
+        Frag d1f[2 * NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 g2, sv_, dx1;
+            load_tile(g2, p.dy2 + tt * d, nt, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f0 = 32 * nt + 8 * q + 4 * h;
+                const int ip = (f0 % l.hd) / 2;
+                const float2 c = *reinterpret_cast<const float2*>(p.cs + pos * (l.hd / 2) + ip);
+                const float2 sn = *reinterpret_cast<const float2*>(p.sn + pos * (l.hd / 2) + ip);
+                const float ge0 = ds[nt][4 * q] + g2[4 * q] * c.x + g2[4 * q + 1] * sn.x;
+                const float go0 = ds[nt][4 * q + 1] - g2[4 * q] * sn.x + g2[4 * q + 1] * c.x;
+                const float ge1 = ds[nt][4 * q + 2] + g2[4 * q + 2] * c.y + g2[4 * q + 3] * sn.y;
+                const float go1 = ds[nt][4 * q + 3] - g2[4 * q + 2] * sn.y + g2[4 * q + 3] * c.y;
+                dx1[4 * q] = ge0 * silu_grad_(x1[nt][4 * q]) * live;
+                dx1[4 * q + 1] = go0 * silu_grad_(x1[nt][4 * q + 1]) * live;
+                dx1[4 * q + 2] = ge1 * silu_grad_(x1[nt][4 * q + 2]) * live;
+                dx1[4 * q + 3] = go1 * silu_grad_(x1[nt][4 * q + 3]) * live;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv_[r] = silu_(x1[nt][r]);
+            if (ok) {
+                store_tile(sv_, p.s + t * d, nt, h);
+                store_tile(dx1, p.dx1 + t * d, nt, h);
+                store_tile(n[nt], p.n + t * d, nt, h);
+            }
+            tile_frags(dx1, d1f[2 * nt], d1f[2 * nt + 1]);
+        }
+        // dn = (W1^T dx1) * mask (+ dm in the first block: m = n + ...);  RMSNorm1 backward;  dx = dxd * drop + c dm
+        f32x16 dn[NT], sc1[NT], dmv[NT];
+        float dot = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            zero(dn[nt]);
+#pragma unroll
+            for (int ks = 0; ks < 2 * NT; ++ks) mma(dn[nt], p.pk + l.w1t, nt, 2 * NT, ks, d1f[ks], lane);
+            load_tile(dmv[nt], p.dm + tt * d, nt, h);
+            load_tile(sc1[nt], p.scale1, nt, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dmv[nt][r] *= live;
+                dn[nt][r] = dn[nt][r] * mk + (p.first ? dmv[nt][r] : 0.f);
+                dot += dn[nt][r] * sc1[nt][r] * xd[nt][r];
+            }
+        }
+        dot = pair_sum(dot);
+        const float coef = dot * rstd * rstd / (float)d;
+        const float cres = p.first ? 1.f : 2.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 dxv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dsc[nt][r] += dn[nt][r] * xd[nt][r] * rstd;
+                dxv[r] = rstd * (sc1[nt][r] * dn[nt][r] - xd[nt][r] * coef);
+            }
+            if (p.drop != nullptr) {
+                f32x16 dr;
+                load_tile(dr, p.drop + tt * d, nt, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dxv[r] *= dr[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dxv[r] += cres * dmv[nt][r];
+            if (ok) store_tile(dxv, p.dx + t * d, nt, h);
+        }
+    }
+    write_scale_partial<NT>(dsc, p.dscale_part + ((int64_t)blockIdx.x * 4 + wave) * d, lane);
+}
+
+inline int block_grid(int64_t T) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(hmx_ceil_div(T, 32), 4), 2048)); }
+
+bool shape_ok(int64_t d, int64_t H) {
+    if (H <= 0 || d <= 0 || d % H) return false;
+    const int64_t hd = d / H;
+    return d % 32 == 0 && d <= 32 * kMaxNT && hd % 32 == 0 && H <= 8;
+}
+
+#define HMX_BLOCK_DISPATCH(KERNEL, grid, stream, p)                                                                  \
+    switch ((p).lay.NT) {                                                                                            \
+        case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(256), 0, stream, p); break;                         \
+        case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(256), 0, stream, p); break;                         \
+        case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(256), 0, stream, p); break;                         \
+        default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, stream, p); break;                        \
+    }
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" int hmx_block_supported(int64_t d, int64_t H) { return shape_ok(d, H) ? 1 : 0; }
+
+extern "C" size_t hmx_block_packed_bytes(int64_t d, int64_t H) {
+    if (!shape_ok(d, H)) return 0;
+    return make_layout((int)d, (int)H).total * sizeof(uint4);
+}
+
+extern "C" int64_t hmx_block_scale_partial_rows(int64_t T) { return (int64_t)block_grid(T) * 4; }
+
+extern "C" int hmx_block_pack_f32(const hmx_block_weights* w, int64_t d, int64_t H, void* packed, void* stream) {
+    HMX_ENTER();
+    if (!w || !packed || !shape_ok(d, H)) return HMX_EINVAL;
+    if (!w->W1 || !w->W2 || !w->Wg || !w->Wu || !w->Wd) return HMX_EINVAL;
+    const PackLayout l = make_layout((int)d, (int)H);
+    PackParams p{};
+    int n = 0;
+    auto add = [&](const float* W, int64_t rs, int64_t cs, int N, int K, size_t out) { p.job[n++] = PackJob{W, rs, cs, N, K, out}; };
+    const int D = (int)d;
+    add(w->W1, D, 1, D, D, l.w1); add(w->W2, D, 1, D, D, l.w2); add(w->Wg, D, 1, D, D, l.wg);
+    add(w->Wu, D, 1, D, D, l.wu); add(w->Wd, D, 1, D, D, l.wd);
+    add(w->W1, 1, D, D, D, l.w1t); add(w->W2, 1, D, D, D, l.w2t); add(w->Wg, 1, D, D, D, l.wgt);
+    add(w->Wu, 1, D, D, D, l.wut); add(w->Wd, 1, D, D, D, l.wdt);
+    for (int hh = 0; hh < (int)H; ++hh) {
+        if (!w->Win[hh] || !w->Wout[hh]) return HMX_EINVAL;
+        add(w->Win[hh], l.hd, 1, 2 * l.ED, l.hd, l.win + hh * l.win_stride);            // (2 ED, hd)
+        add(w->Win[hh], 1, l.hd, l.hd, 2 * l.ED, l.wint + hh * l.wint_stride);          // transposed: (hd, 2 ED)
+        add(w->Wout[hh], l.ED, 1, l.hd, l.ED, l.wout + hh * l.wout_stride);             // (hd, ED)
+        add(w->Wout[hh], 1, l.ED, l.ED, l.hd, l.woutt + hh * l.woutt_stride);           // transposed: (ED, hd)
+    }
+    p.n_jobs = n;
+    p.out = static_cast<uint4*>(packed);
+    hipLaunchKernelGGL(block_pack_kernel, dim3(8, n), dim3(256), 0, (hipStream_t)stream, p);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+static bool fill_common(BlockParams& p, const hmx_block_args* a) {
+    if (!a || !shape_ok(a->d, a->H) || a->T < 0 || a->L <= 0 || !a->packed) return false;
+    p = BlockParams{};
+    p.T = a->T; p.L = (int)a->L; p.first = a->first; p.eps = a->eps;
+    p.inv_sqrt_h = 1.0f / sqrtf((float)a->H);
+    p.lay = make_layout((int)a->d, (int)a->H);
+    p.pk = static_cast<const uint4*>(a->packed);
+    p.mask = a->mask; p.x = a->x; p.drop = a->drop; p.scale1 = a->scale1; p.b1 = a->b1; p.cs = a->rope_cos; p.sn = a->rope_sin;
+    p.rstd1 = a->rstd1; p.x_in = a->x_in; p.z = a->z; p.y2 = a->y2; p.yg = a->yg; p.b2 = a->b2; p.scale2 = a->scale2;
+    p.out = a->out; p.m = a->m; p.rstd2 = a->rstd2; p.dout = a->dout; p.dyg = a->dyg; p.dy2 = a->dy2; p.dm = a->dm;
+    p.hmid = a->hmid; p.n2 = a->n2; p.dg = a->dg; p.du = a->du; p.p = a->p; p.dy1 = a->dy1; p.dscale_part = a->dscale_part;
+    p.dx_in = a->dx_in; p.dz = a->dz; p.dx = a->dx; p.s = a->s; p.dx1 = a->dx1; p.n = a->n;
+    return true;
+}
+
+extern "C" int hmx_block_pre_fwd(const hmx_block_args* a, void* stream) {
+    HMX_ENTER();
+    BlockParams p;
+    if (!fill_common(p, a)) return HMX_EINVAL;
+    if (p.T == 0) return HMX_OK;
+    if (!p.x || !p.scale1 || !p.b1 || !p.cs || !p.sn || !p.rstd1 || !p.x_in || !p.z || !p.y2) return HMX_EINVAL;
+    HMX_BLOCK_DISPATCH(block_pre_fwd_kernel, block_grid(p.T), (hipStream_t)stream, p);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_block_post_fwd(const hmx_block_args* a, void* stream) {
+    HMX_ENTER();
+    BlockParams p;
+    if (!fill_common(p, a)) return HMX_EINVAL;
+    if (p.T == 0) return HMX_OK;
+    if (!p.yg || !p.y2 || !p.x || !p.b2 || !p.scale2 || !p.out || !p.m || !p.rstd2 || (p.first && (!p.rstd1 || !p.scale1)))
+        return HMX_EINVAL;
+    HMX_BLOCK_DISPATCH(block_post_fwd_kernel, block_grid(p.T), (hipStream_t)stream, p);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_block_post_bwd(const hmx_block_args* a, void* stream) {
+    HMX_ENTER();
+    BlockParams p;
+    if (!fill_common(p, a)) return HMX_EINVAL;
+    if (p.T == 0) return HMX_OK;
+    if (!p.dout || !p.m || !p.rstd2 || !p.scale2 || !p.yg || !p.y2 || !p.dyg || !p.dy2 || !p.dm || !p.hmid || !p.n2 || !p.dg ||
+        !p.du || !p.p || !p.dy1 || !p.dscale_part)
+        return HMX_EINVAL;
+    HMX_BLOCK_DISPATCH(block_post_bwd_kernel, block_grid(p.T), (hipStream_t)stream, p);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_block_pre_bwd(const hmx_block_args* a, void* stream) {
+    HMX_ENTER();
+    BlockParams p;
+    if (!fill_common(p, a)) return HMX_EINVAL;
+    if (p.T == 0) return HMX_OK;
+    if (!p.x || !p.scale1 || !p.b1 || !p.cs || !p.sn || !p.dx_in || !p.dz || !p.dy2 || !p.dm || !p.dx || !p.s || !p.dx1 || !p.n ||
+        !p.dscale_part)
+        return HMX_EINVAL;
+    HMX_BLOCK_DISPATCH(block_pre_bwd_kernel, block_grid(p.T), (hipStream_t)stream, p);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}

@@ -20,6 +20,24 @@ class WgradDesc(ctypes.Structure):
                 ("dbias", c_void_p), ("accumulate", c_int32)]
 
 
+class BlockWeights(ctypes.Structure):
+    """hmx_block_weights of include/hmx.h."""
+    _fields_ = [(n, c_void_p) for n in ("W1", "W2", "Wg", "Wu", "Wd")] + [("Win", c_void_p * 8), ("Wout", c_void_p * 8)]
+
+
+_BLOCK_PTRS_IN = ("mask", "x", "drop", "scale1", "b1", "rope_cos", "rope_sin")
+
+
+class BlockArgs(ctypes.Structure):
+    """hmx_block_args of include/hmx.h."""
+    _fields_ = ([("T", c_int64), ("L", c_int64), ("d", c_int64), ("H", c_int64), ("first", c_int32), ("eps", c_float),
+                 ("packed", c_void_p)] +
+                [(n, c_void_p) for n in ("mask", "x", "drop", "scale1", "b1", "rope_cos", "rope_sin",
+                                         "rstd1", "x_in", "z", "y2", "yg", "b2", "scale2", "out", "m", "rstd2", "dout",
+                                         "dyg", "dy2", "dm", "hmid", "n2", "dg", "du", "p", "dy1", "dscale_part",
+                                         "dx_in", "dz", "dx", "s", "dx1", "n")])
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/hmx.h
 PROTOTYPES = {
     "hmx_abi_version": (c_int, []),
@@ -70,6 +88,14 @@ PROTOTYPES = {
     "hmx_scan_state_floats": (I64, [I64, I64, I64]),
     "hmx_scan_bwd": (c_int, [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, P]),
     "hmx_sum_groups_f32": (c_int, [P, I64, I64, I64, P, P]),
+    "hmx_block_supported": (c_int, [I64, I64]),
+    "hmx_block_packed_bytes": (c_size_t, [I64, I64]),
+    "hmx_block_scale_partial_rows": (I64, [I64]),
+    "hmx_block_pack_f32": (c_int, [ctypes.POINTER(BlockWeights), I64, I64, P, P]),
+    "hmx_block_pre_fwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
+    "hmx_block_post_fwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
+    "hmx_block_post_bwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
+    "hmx_block_pre_bwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
     "hmx_profile_enable": (c_int, [c_int]),
     "hmx_profile_collect": (c_int, [c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }
@@ -124,6 +150,12 @@ def profile_collect(tag):
     return ms.value, n.value
 
 
+SPLIT_BF16 = True
+
+
 def set_linear_precision(split_bf16=True):
-    """True (default): split-bf16 projections (fp32-class accuracy); False: single bf16 MFMA per product."""
+    """True (default): split-bf16 projections (fp32-class accuracy); False: single bf16 MFMA per product (the fused
+    block kernels are split-bf16 only: in single mode blocks run on the per-operation kernels)."""
+    global SPLIT_BF16
     check(lib().hmx_set_linear_precision(1 if split_bf16 else 0), "hmx_set_linear_precision")
+    SPLIT_BF16 = bool(split_bf16)

@@ -10,12 +10,15 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import block_ops
 from . import enc_ops as E
+from . import hmx
 from . import ops
 from .enc_ops import pscan, selective_scan   # noqa: F401  (hydra3.py:104, 107: same names, same call shapes)
 from .shared_embedding import SharedEmbeddingConfig, SharedEmbeddingModule
 
 D_STATE, DT_RANK, D_CONV = 16, 16, 4
+FUSED_BLOCKS = True      # HydraBlock(First) on the fused block kernels where the shape allows (d, d / heads multiples of 32)
 
 
 class RMSNorm(nn.Module):
@@ -134,6 +137,9 @@ class _HydraBlockBase(nn.Module):
         x2 = x.reshape(T, d)
         m1 = padding_mask.reshape(T).contiguous() if padding_mask is not None else None
         mhm = self.multiheadMamba
+        if FUSED_BLOCKS and x2.is_cuda and hmx.SPLIT_BF16 and block_ops.supported(d, len(mhm.mamba)):
+            # the block as two fused token-parallel kernels around the conv / scan core
+            return block_ops.hydra_block(self, x2.contiguous(), m1, L, self.first).view(B, L, d)
         n = E.rmsnorm(self.dropout(x2), self.norm1.scale, self.norm1.eps)
         p = mhm.mix(n, m1, L)
         # mixer output x_org + W2 p + b2, plus the block's residual: n (first block) or x again (regular block)

@@ -305,6 +305,51 @@ int hmx_scan_bwd(const float* xc, const float* z, const float* dbc, const float*
 int hmx_sum_groups_f32(const float* part, int64_t rows, int64_t groups, int64_t width, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Fused halves of a Hydra block (HydraBlockFirst / HydraBlock, hydra3.py:392-457, with MultiHeadMamba :359-389).
+ * Everything of a block that has no dependence between tokens runs in two kernels per direction:
+ *   pre  half: dropout multiplier, RMSNorm1, linear_layer1 (+ bias, input mask), SiLU, RoPE branch (y2), in_proj of
+ *              every head (x_in, z)                                   (hydra3.py:411-412 / 445-446, 366-386, 263-265)
+ *   post half: out_proj of every head, y1 * y2 / sqrt(H), linear_layer2 + bias + x_org + block residual, RMSNorm2,
+ *              down(SiLU(gate) * up) + residual, output mask          (hydra3.py:275, 387-388, 413-423 / 447-457)
+ * The causal conv, deltaBC projection and selective scan between the halves stay sequence kernels.
+ * Weights are packed once per forward pass (hmx_block_pack_f32: bf16 hi / lo fragments, both orientations) into a
+ * buffer of hmx_block_packed_bytes(d, H).  Supported shapes: hmx_block_supported(d, H) (d and d / H multiples of 32,
+ * d <= 128, H <= 8); other shapes use the per-operation entry points above.
+ * The backward halves recompute the intermediates they need from (x, m, rstd2, yg, y2), write the input gradients
+ * (dyg, dy2, dm; then dx) and the operand pairs of every weight gradient (hmid, n2, dg, du, p, dy1; s, dx1, n) for
+ * hmx_linear_wgrad_batch_f32, plus per-wave partials of the two RMSNorm scale gradients, shaped
+ * (hmx_block_scale_partial_rows(T), d) (sum with hmx_colsum_f32).
+ * One argument block serves the four calls; each reads the fields its half needs.
+ * ------------------------------------------------------------------------------- */
+typedef struct hmx_block_weights {
+    const float *W1, *W2, *Wg, *Wu, *Wd;   /* linear_layer1, linear_layer2, gate, up, down: (d, d)          */
+    const float* Win[8];                   /* per head in_proj (2 * ED, hd), rows [x | z]                   */
+    const float* Wout[8];                  /* per head out_proj (hd, ED)                                    */
+} hmx_block_weights;
+typedef struct hmx_block_args {
+    int64_t T, L, d, H;
+    int32_t first;                         /* 1: HydraBlockFirst residual wiring, 0: HydraBlock             */
+    float eps;
+    const void* packed;
+    const float *mask, *x, *drop, *scale1, *b1, *rope_cos, *rope_sin;   /* drop (T, d) multiplier or NULL   */
+    float *rstd1, *x_in, *z, *y2;          /* pre forward outputs: (T), (T, H*ED), (T, H*ED), (T, d)        */
+    const float *yg, *b2, *scale2;         /* post forward inputs: gated scan output (T, H*ED)              */
+    float *out, *m, *rstd2;                /* post forward outputs: (T, d), (T, d), (T)                     */
+    const float* dout;                     /* post backward input (T, d)                                    */
+    float *dyg, *dy2, *dm, *hmid, *n2, *dg, *du, *p, *dy1, *dscale_part;
+    const float *dx_in, *dz;               /* pre backward inputs (T, H*ED) each                            */
+    float *dx, *s, *dx1, *n;
+} hmx_block_args;
+int hmx_block_supported(int64_t d, int64_t H);
+size_t hmx_block_packed_bytes(int64_t d, int64_t H);
+int64_t hmx_block_scale_partial_rows(int64_t T);
+int hmx_block_pack_f32(const hmx_block_weights* w, int64_t d, int64_t H, void* packed, void* stream);
+int hmx_block_pre_fwd(const hmx_block_args* a, void* stream);
+int hmx_block_post_fwd(const hmx_block_args* a, void* stream);
+int hmx_block_post_bwd(const hmx_block_args* a, void* stream);
+int hmx_block_pre_bwd(const hmx_block_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Benchmark support (no counterpart in the reference).  When enabled, entry points bracket
  * their dominant kernel with HIP events on the caller's stream; hmx_profile_collect blocks
  * until the events of spans tagged `tag` have completed, returns their summed duration and
