@@ -66,7 +66,10 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     ops_mod.set_fused_table_grad(True)     # table gradients accumulate straight into .grad (same sums, fewer passes)
     from generative_recommenders_amd import enc_ops
     enc_ops.set_direct_param_grad(True)    # weight gradients of the projections: batched launches adding into .grad
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1)
+    # main.py:640 builds torch.optim.AdamW(lr, betas=(0.9, 0.98), weight_decay=0.1); fused=True selects PyTorch's
+    # single-kernel implementation of the same update (one pass over the 1.28 GB of tables instead of nine)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1,
+                            fused=not getattr(args, "foreach_adamw", False))
     bt = synth.train_batch(B, L, args.users, args.items, dev, seed=99 + rank)
     feat = [[] for _ in range(B)]
     sync_grads = None
@@ -150,7 +153,8 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                                 " (configs[4], per GPU)" if (L, d) == (512, 128) else ""),
                    "batch_per_gpu": B, "seq_len": L, "d": d, "users": args.users, "items": args.items,
                    "includes": "zero_grad, forward (encoder + miner top-50 + fused InfoNCE), backward, "
-                               "clip_grad_norm, AdamW; table gradients accumulated directly into .grad. Not evaluated: "
+                               "clip_grad_norm, AdamW (torch.optim.AdamW(fused=True)); table and projection-weight gradients "
+                               "accumulated directly into .grad. Not evaluated: "
                                "the neg_seqs gather + projection and the diversity term, which the reference computes "
                                "and multiplies by its default weights 0.0 (hydra3.py:694-696,711,1146-1149): two row "
                                "gathers per step here (seq, pos), three in the reference",

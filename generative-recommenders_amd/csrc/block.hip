@@ -70,11 +70,30 @@ __device__ __forceinline__ Frag row_frag(const float* row, int ks, int h) {
     return make_frag(v);
 }
 
-// acc += W(tile nt, k-step ks) * B   with W packed as [(nt * KS + ks) * 2 + part][lane] 16-byte entries
-__device__ __forceinline__ void mma(f32x16& acc, const uint4* pk, int nt, int KS, int ks, const Frag& b, int lane) {
-    const uint4* e = pk + ((size_t)(nt * KS + ks) * 2) * 64 + lane;
-    const short8 a_hi = __builtin_bit_cast(short8, e[0]);
-    const short8 a_lo = __builtin_bit_cast(short8, e[64]);
+// Where a kernel reads packed weights from: the pack buffer in global memory (L2), or -- for the entry range
+// [lo, hi) that the workgroup copied at its start -- LDS.
+extern __shared__ __attribute__((aligned(16))) uint4 w_lds[];
+template <bool LDSW>
+struct WSrc {
+    const uint4* g;
+    unsigned lo, hi;
+};
+
+// acc += W(tile nt, k-step ks) * B   with W packed as [(nt * KS + ks) * 2 + part][lane] 16-byte entries starting at
+// entry `w` of the pack buffer
+template <bool LDSW>
+__device__ __forceinline__ void mma(f32x16& acc, const WSrc<LDSW>& src, size_t w, int nt, int KS, int ks, const Frag& b, int lane) {
+    const unsigned base = (unsigned)w + (unsigned)(nt * KS + ks) * 128u;      // wave-uniform
+    uint4 e0, e1;
+    if (LDSW && base >= src.lo && base < src.hi) {
+        e0 = w_lds[base - src.lo + lane];
+        e1 = w_lds[base - src.lo + 64 + lane];
+    } else {
+        e0 = src.g[base + lane];
+        e1 = src.g[base + 64 + lane];
+    }
+    const short8 a_hi = __builtin_bit_cast(short8, e0);
+    const short8 a_lo = __builtin_bit_cast(short8, e1);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b.hi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b.hi, acc, 0, 0, 0);
@@ -121,11 +140,14 @@ __host__ __device__ inline PackLayout make_layout(int d, int H) {
     l.NT = d / 32; l.NTh = l.hd / 32; l.KSd = d / 16; l.KSh = l.hd / 16; l.KSe = l.ED / 16; l.KSz = 2 * l.ED / 16;
     size_t o = 0;
     const size_t dd = pack_entries(d, d);
-    l.w1 = o; o += dd; l.w2 = o; o += dd; l.wg = o; o += dd; l.wu = o; o += dd; l.wd = o; o += dd;
+    // Order: what one kernel reads most is contiguous, so that it can sit in LDS as one range:
+    //   pre forward [win .. w1], pre backward [w1 .. wint], post forward [wout .. wu], post backward [wg .. w2t]
     l.win_stride = pack_entries(2 * l.ED, l.hd); l.win = o; o += l.win_stride * H;
-    l.wout_stride = pack_entries(l.hd, l.ED); l.wout = o; o += l.wout_stride * H;
-    l.w1t = o; o += dd; l.w2t = o; o += dd; l.wgt = o; o += dd; l.wut = o; o += dd; l.wdt = o; o += dd;
+    l.w1 = o; o += dd; l.w1t = o; o += dd;
     l.wint_stride = pack_entries(l.hd, 2 * l.ED); l.wint = o; o += l.wint_stride * H;
+    l.wout_stride = pack_entries(l.hd, l.ED); l.wout = o; o += l.wout_stride * H;
+    l.w2 = o; o += dd; l.wd = o; o += dd; l.wg = o; o += dd; l.wu = o; o += dd;
+    l.wdt = o; o += dd; l.wgt = o; o += dd; l.wut = o; o += dd; l.w2t = o; o += dd;
     l.woutt_stride = pack_entries(l.ED, l.hd); l.woutt = o; o += l.woutt_stride * H;
     l.total = o;
     return l;
@@ -172,6 +194,7 @@ struct BlockParams {
     float eps, inv_sqrt_h;
     PackLayout lay;
     const uint4* pk;
+    unsigned lds_lo, lds_hi;  // entry range of the pack buffer a workgroup keeps in LDS (template flag LDSW)
     const float* mask;      // (T)
     // pre half
     const float* x;         // (T, d) block input
@@ -244,8 +267,9 @@ __device__ __forceinline__ float norm1(const BlockParams& p, const float* xrow, 
 }
 
 // x1 = W1 (n * mask) + b1
-template <int NT>
-__device__ __forceinline__ void linear1(const BlockParams& p, const f32x16 (&n)[NT], float mk, int h, int lane, f32x16 (&x1)[NT]) {
+template <int NT, bool LDSW>
+__device__ __forceinline__ void linear1(const BlockParams& p, const WSrc<LDSW>& src, const f32x16 (&n)[NT], float mk, int h, int lane,
+                                        f32x16 (&x1)[NT]) {
     Frag nf[2 * NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -258,15 +282,20 @@ __device__ __forceinline__ void linear1(const BlockParams& p, const f32x16 (&n)[
     for (int nt = 0; nt < NT; ++nt) {
         load_tile(x1[nt], p.b1, nt, h);
 #pragma unroll
-        for (int ks = 0; ks < 2 * NT; ++ks) mma(x1[nt], p.pk + p.lay.w1, nt, 2 * NT, ks, nf[ks], lane);
+        for (int ks = 0; ks < 2 * NT; ++ks) mma<LDSW>(x1[nt], src, p.lay.w1, nt, 2 * NT, ks, nf[ks], lane);
     }
 }
 
 // ------------------------------------------------------------------ pre half, forward
-template <int NT>
+template <int NT, bool LDSW>
 __global__ __launch_bounds__(256) void block_pre_fwd_kernel(BlockParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const PackLayout& l = p.lay;
+    const WSrc<LDSW> src{p.pk, p.lds_lo, p.lds_hi};
+    if (LDSW) {
+        for (unsigned idx = threadIdx.x; idx < p.lds_hi - p.lds_lo; idx += 256) w_lds[idx] = p.pk[p.lds_lo + idx];
+        __syncthreads();
+    }
     const int d = 32 * NT, C = l.H * l.ED;
     const int64_t n_tiles = hmx_ceil_div(p.T, 32);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
@@ -275,7 +304,7 @@ __global__ __launch_bounds__(256) void block_pre_fwd_kernel(BlockParams p) {
         const int64_t tt = ok ? t : p.T - 1;
         f32x16 xd[NT], n[NT], x1[NT];
         const float rstd = norm1<NT>(p, p.x + tt * d, p.drop ? p.drop + tt * d : nullptr, h, xd, n);
-        linear1<NT>(p, n, p.mask ? p.mask[tt] : 1.f, h, lane, x1);
+        linear1<NT, LDSW>(p, src, n, p.mask ? p.mask[tt] : 1.f, h, lane, x1);
         // s = SiLU(x1) (kept in x1), y2 = RoPE(s): pairs (2 i, 2 i + 1) are registers (e, e + 1), e even
         const int pos = (int)(tt % p.L);
 #pragma unroll
@@ -304,14 +333,14 @@ __global__ __launch_bounds__(256) void block_pre_fwd_kernel(BlockParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int hh = 0; hh < l.H; ++hh) {
-            const uint4* w = p.pk + l.win + hh * l.win_stride;
+            const size_t w = l.win + hh * l.win_stride;
 #pragma unroll 1
             for (int ot = 0; ot < 2 * l.ED / 32; ++ot) {
                 f32x16 acc;
                 zero(acc);
 #pragma unroll
                 for (int ks = 0; ks < 2 * NT; ++ks)
-                    if (ks >= hh * l.KSh && ks < (hh + 1) * l.KSh) mma(acc, w, ot, l.KSh, ks - hh * l.KSh, sf[ks], lane);
+                    if (ks >= hh * l.KSh && ks < (hh + 1) * l.KSh) mma<LDSW>(acc, src, w, ot, l.KSh, ks - hh * l.KSh, sf[ks], lane);
                 if (ok) {
                     const int ch = ot * 32;
                     float* dst = (ch < l.ED ? p.x_in : p.z) + t * C + hh * l.ED + (ch < l.ED ? ch : ch - l.ED);
@@ -325,28 +354,34 @@ __global__ __launch_bounds__(256) void block_pre_fwd_kernel(BlockParams p) {
 
 // ------------------------------------------------------------------ post half, forward
 // y1 = Wout_h yg_h for every head (feature tiles of head h: [h * NTh, (h + 1) * NTh))
-template <int NT>
-__device__ __forceinline__ void out_proj(const BlockParams& p, const float* ygrow, int h, int lane, f32x16 (&y1)[NT]) {
+template <int NT, bool LDSW>
+__device__ __forceinline__ void out_proj(const BlockParams& p, const WSrc<LDSW>& src, const float* ygrow, int h, int lane,
+                                         f32x16 (&y1)[NT]) {
     const PackLayout& l = p.lay;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) zero(y1[nt]);
 #pragma unroll 1
     for (int hh = 0; hh < l.H; ++hh) {
-        const uint4* w = p.pk + l.wout + hh * l.wout_stride;
+        const size_t w = l.wout + hh * l.wout_stride;
 
         for (int ks = 0; ks < l.KSe; ++ks) {
             const Frag f = row_frag(ygrow + hh * l.ED, ks, h);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh) mma(y1[nt], w, nt - hh * l.NTh, l.KSe, ks, f, lane);
+                if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh) mma<LDSW>(y1[nt], src, w, nt - hh * l.NTh, l.KSe, ks, f, lane);
         }
     }
 }
 
-template <int NT>
+template <int NT, bool LDSW>
 __global__ __launch_bounds__(256) void block_post_fwd_kernel(BlockParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const PackLayout& l = p.lay;
+    const WSrc<LDSW> src{p.pk, p.lds_lo, p.lds_hi};
+    if (LDSW) {
+        for (unsigned idx = threadIdx.x; idx < p.lds_hi - p.lds_lo; idx += 256) w_lds[idx] = p.pk[p.lds_lo + idx];
+        __syncthreads();
+    }
     const int d = 32 * NT, C = l.H * l.ED;
     const int64_t n_tiles = hmx_ceil_div(p.T, 32);
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(256) void block_post_fwd_kernel(BlockParams p) {
         f32x16 m[NT];
         {
             f32x16 y1[NT];
-            out_proj<NT>(p, p.yg + tt * C, h, lane, y1);
+            out_proj<NT, LDSW>(p, src, p.yg + tt * C, h, lane, y1);
             Frag pf[2 * NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {      // p = y1 * y2 / sqrt(H)
@@ -373,7 +408,7 @@ __global__ __launch_bounds__(256) void block_post_fwd_kernel(BlockParams p) {
             for (int nt = 0; nt < NT; ++nt) {
                 load_tile(m[nt], p.b2, nt, h);
 #pragma unroll
-                for (int ks = 0; ks < 2 * NT; ++ks) mma(m[nt], p.pk + l.w2, nt, 2 * NT, ks, pf[ks], lane);
+                for (int ks = 0; ks < 2 * NT; ++ks) mma<LDSW>(m[nt], src, l.w2, nt, 2 * NT, ks, pf[ks], lane);
                 f32x16 xv;
                 load_tile(xv, p.x + tt * d, nt, h);
                 if (p.first) {
@@ -425,8 +460,8 @@ __global__ __launch_bounds__(256) void block_post_fwd_kernel(BlockParams p) {
             zero(u);
 #pragma unroll
             for (int ks = 0; ks < 2 * NT; ++ks) {
-                mma(g, p.pk + l.wg, ht, 2 * NT, ks, nf[ks], lane);
-                mma(u, p.pk + l.wu, ht, 2 * NT, ks, nf[ks], lane);
+                mma<LDSW>(g, src, l.wg, ht, 2 * NT, ks, nf[ks], lane);
+                mma<LDSW>(u, src, l.wu, ht, 2 * NT, ks, nf[ks], lane);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[r] = silu_(g[r]) * u[r];
@@ -434,8 +469,8 @@ __global__ __launch_bounds__(256) void block_post_fwd_kernel(BlockParams p) {
             tile_frags(g, h0, h1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                mma(o[nt], p.pk + l.wd, nt, 2 * NT, 2 * ht, h0, lane);
-                mma(o[nt], p.pk + l.wd, nt, 2 * NT, 2 * ht + 1, h1, lane);
+                mma<LDSW>(o[nt], src, l.wd, nt, 2 * NT, 2 * ht, h0, lane);
+                mma<LDSW>(o[nt], src, l.wd, nt, 2 * NT, 2 * ht + 1, h1, lane);
             }
         }
         if (ok) {
@@ -467,10 +502,15 @@ __device__ __forceinline__ void write_scale_partial(const f32x16 (&acc)[NT], flo
 }
 
 // ------------------------------------------------------------------ post half, backward
-template <int NT>
+template <int NT, bool LDSW>
 __global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const PackLayout& l = p.lay;
+    const WSrc<LDSW> src{p.pk, p.lds_lo, p.lds_hi};
+    if (LDSW) {
+        for (unsigned idx = threadIdx.x; idx < p.lds_hi - p.lds_lo; idx += 256) w_lds[idx] = p.pk[p.lds_lo + idx];
+        __syncthreads();
+    }
     const int d = 32 * NT, C = l.H * l.ED;
     const int64_t n_tiles = hmx_ceil_div(p.T, 32);
     f32x16 dsc[NT];
@@ -512,9 +552,9 @@ __global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
             zero(dh);
 #pragma unroll
             for (int ks = 0; ks < 2 * NT; ++ks) {
-                mma(g, p.pk + l.wg, ht, 2 * NT, ks, nf[ks], lane);
-                mma(u, p.pk + l.wu, ht, 2 * NT, ks, nf[ks], lane);
-                mma(dh, p.pk + l.wdt, ht, 2 * NT, ks, dof[ks], lane);
+                mma<LDSW>(g, src, l.wg, ht, 2 * NT, ks, nf[ks], lane);
+                mma<LDSW>(u, src, l.wu, ht, 2 * NT, ks, nf[ks], lane);
+                mma<LDSW>(dh, src, l.wdt, ht, 2 * NT, ks, dof[ks], lane);
             }
             f32x16 hm, dg, du;
 #pragma unroll
@@ -534,10 +574,10 @@ __global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
             tile_frags(du, u0, u1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                mma(dn2[nt], p.pk + l.wgt, nt, 2 * NT, 2 * ht, g0, lane);
-                mma(dn2[nt], p.pk + l.wgt, nt, 2 * NT, 2 * ht + 1, g1, lane);
-                mma(dn2[nt], p.pk + l.wut, nt, 2 * NT, 2 * ht, u0, lane);
-                mma(dn2[nt], p.pk + l.wut, nt, 2 * NT, 2 * ht + 1, u1, lane);
+                mma<LDSW>(dn2[nt], src, l.wgt, nt, 2 * NT, 2 * ht, g0, lane);
+                mma<LDSW>(dn2[nt], src, l.wgt, nt, 2 * NT, 2 * ht + 1, g1, lane);
+                mma<LDSW>(dn2[nt], src, l.wut, nt, 2 * NT, 2 * ht, u0, lane);
+                mma<LDSW>(dn2[nt], src, l.wut, nt, 2 * NT, 2 * ht + 1, u1, lane);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -576,14 +616,14 @@ __global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
         __builtin_amdgcn_sched_barrier(0);
         // mixer tail backward: dp = W2^T dm; recompute y1; dy1 = dp y2 / sqrt(H), dy2 = dp y1 / sqrt(H); dyg = Wout^T dy1
         f32x16 y1[NT];
-        out_proj<NT>(p, p.yg + tt * C, h, lane, y1);
+        out_proj<NT, LDSW>(p, src, p.yg + tt * C, h, lane, y1);
         Frag d1f[2 * NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x16 dp, y2;
             zero(dp);
 #pragma unroll
-            for (int ks = 0; ks < 2 * NT; ++ks) mma(dp, p.pk + l.w2t, nt, 2 * NT, ks, dmf[ks], lane);
+            for (int ks = 0; ks < 2 * NT; ++ks) mma<LDSW>(dp, src, l.w2t, nt, 2 * NT, ks, dmf[ks], lane);
             load_tile(y2, p.y2 + tt * d, nt, h);
             f32x16 dy1, dy2, pp;
 #pragma unroll
@@ -602,14 +642,14 @@ __global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int hh = 0; hh < l.H; ++hh) {
-            const uint4* w = p.pk + l.woutt + hh * l.woutt_stride;
+            const size_t w = l.woutt + hh * l.woutt_stride;
 #pragma unroll 1
             for (int ot = 0; ot < l.ED / 32; ++ot) {
                 f32x16 acc;
                 zero(acc);
 #pragma unroll
                 for (int ks = 0; ks < 2 * NT; ++ks)
-                    if (ks >= hh * l.KSh && ks < (hh + 1) * l.KSh) mma(acc, w, ot, l.KSh, ks - hh * l.KSh, d1f[ks], lane);
+                    if (ks >= hh * l.KSh && ks < (hh + 1) * l.KSh) mma<LDSW>(acc, src, w, ot, l.KSh, ks - hh * l.KSh, d1f[ks], lane);
                 if (ok) store_tile(acc, p.dyg + t * C + hh * l.ED + ot * 32, 0, h);
             }
         }
@@ -618,10 +658,15 @@ __global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
 }
 
 // ------------------------------------------------------------------ pre half, backward
-template <int NT>
+template <int NT, bool LDSW>
 __global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const PackLayout& l = p.lay;
+    const WSrc<LDSW> src{p.pk, p.lds_lo, p.lds_hi};
+    if (LDSW) {
+        for (unsigned idx = threadIdx.x; idx < p.lds_hi - p.lds_lo; idx += 256) w_lds[idx] = p.pk[p.lds_lo + idx];
+        __syncthreads();
+    }
     const int d = 32 * NT, C = l.H * l.ED;
     const int64_t n_tiles = hmx_ceil_div(p.T, 32);
     f32x16 dsc[NT];
@@ -635,7 +680,7 @@ __global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
         const float mk = p.mask ? p.mask[tt] : 1.f;
         f32x16 xd[NT], n[NT], x1[NT];
         const float rstd = norm1<NT>(p, p.x + tt * d, p.drop ? p.drop + tt * d : nullptr, h, xd, n);
-        linear1<NT>(p, n, mk, h, lane, x1);
+        linear1<NT, LDSW>(p, src, n, mk, h, lane, x1);
         // ds = sum_heads Win_h^T [dx_in_h ; dz_h]
         f32x16 ds[NT];
 #pragma unroll
@@ -643,14 +688,14 @@ __global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int hh = 0; hh < l.H; ++hh) {
-            const uint4* w = p.pk + l.wint + hh * l.wint_stride;
+            const size_t w = l.wint + hh * l.wint_stride;
 
             for (int ks = 0; ks < l.KSz; ++ks) {
-                const float* src = (ks < l.KSe ? p.dx_in : p.dz) + tt * C + hh * l.ED;
-                const Frag f = row_frag(src, ks < l.KSe ? ks : ks - l.KSe, h);
+                const float* grow = (ks < l.KSe ? p.dx_in : p.dz) + tt * C + hh * l.ED;
+                const Frag f = row_frag(grow, ks < l.KSe ? ks : ks - l.KSe, h);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh) mma(ds[nt], w, nt - hh * l.NTh, l.KSz, ks, f, lane);
+                    if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh) mma<LDSW>(ds[nt], src, w, nt - hh * l.NTh, l.KSz, ks, f, lane);
             }
         }
         // + RoPE^T(dy2);  dx1 = ds * SiLU'(x1);  s = SiLU(x1)
@@ -691,7 +736,7 @@ __global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
         for (int nt = 0; nt < NT; ++nt) {
             zero(dn[nt]);
 #pragma unroll
-            for (int ks = 0; ks < 2 * NT; ++ks) mma(dn[nt], p.pk + l.w1t, nt, 2 * NT, ks, d1f[ks], lane);
+            for (int ks = 0; ks < 2 * NT; ++ks) mma<LDSW>(dn[nt], src, l.w1t, nt, 2 * NT, ks, d1f[ks], lane);
             load_tile(dmv[nt], p.dm + tt * d, nt, h);
             load_tile(sc1[nt], p.scale1, nt, h);
 #pragma unroll
@@ -734,12 +779,34 @@ bool shape_ok(int64_t d, int64_t H) {
     return d % 32 == 0 && d <= 32 * kMaxNT && hd % 32 == 0 && H <= 8;
 }
 
-#define HMX_BLOCK_DISPATCH(KERNEL, grid, stream, p)                                                                  \
+constexpr size_t kMaxWeightLds = 128 * 1024;
+
+// Launch KERNEL<NT, LDSW>.  With the entry range [lo, hi) non-empty and small enough, every workgroup keeps it in LDS
+// (the copy is paid once per CU: one workgroup per CU walks the token tiles); otherwise weights come from L2.
+// Measured at d = 64: the backward halves (512 registers, one wave per SIMD either way) gain 7-10 % from LDS weights;
+// the forward halves fit two waves per SIMD without the LDS footprint and are faster that way, so they pass lo = hi.
+#define HMX_BLOCK_LAUNCH(KERNEL, NTV, p, T, lo, hi, stream)                                                          \
+    do {                                                                                                             \
+        const size_t lds_bytes = ((hi) - (lo)) * sizeof(uint4);                                                      \
+        if ((hi) > (lo) && lds_bytes <= kMaxWeightLds) {                                                                            \
+            (p).lds_lo = (unsigned)(lo);                                                                             \
+            (p).lds_hi = (unsigned)(hi);                                                                             \
+            static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<NTV, true>),   \
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWeightLds); \
+            (void)attr_;                                                                                             \
+            hipLaunchKernelGGL((KERNEL<NTV, true>), dim3(std::min(block_grid(T), 256)), dim3(256), lds_bytes, stream, p); \
+        } else {                                                                                                     \
+            (p).lds_lo = (p).lds_hi = 0;                                                                             \
+            hipLaunchKernelGGL((KERNEL<NTV, false>), dim3(std::min(block_grid(T), 1024)), dim3(256), 0, stream, p); \
+        }                                                                                                            \
+    } while (0)
+
+#define HMX_BLOCK_DISPATCH(KERNEL, p, lo, hi, stream)                                                                \
     switch ((p).lay.NT) {                                                                                            \
-        case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(256), 0, stream, p); break;                         \
-        case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(256), 0, stream, p); break;                         \
-        case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(256), 0, stream, p); break;                         \
-        default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, stream, p); break;                        \
+        case 1: HMX_BLOCK_LAUNCH(KERNEL, 1, p, (p).T, lo, hi, stream); break;                                         \
+        case 2: HMX_BLOCK_LAUNCH(KERNEL, 2, p, (p).T, lo, hi, stream); break;                                         \
+        case 3: HMX_BLOCK_LAUNCH(KERNEL, 3, p, (p).T, lo, hi, stream); break;                                         \
+        default: HMX_BLOCK_LAUNCH(KERNEL, 4, p, (p).T, lo, hi, stream); break;                                        \
     }
 
 }  // namespace
@@ -752,7 +819,8 @@ extern "C" size_t hmx_block_packed_bytes(int64_t d, int64_t H) {
     return make_layout((int)d, (int)H).total * sizeof(uint4);
 }
 
-extern "C" int64_t hmx_block_scale_partial_rows(int64_t T) { return (int64_t)block_grid(T) * 4; }
+// waves of a backward launch (one workgroup per CU at most, four waves each): each writes one row of partials
+extern "C" int64_t hmx_block_scale_partial_rows(int64_t T) { return (int64_t)std::min(block_grid(T), 1024) * 4; }
 
 extern "C" int hmx_block_pack_f32(const hmx_block_weights* w, int64_t d, int64_t H, void* packed, void* stream) {
     HMX_ENTER();
@@ -802,7 +870,7 @@ extern "C" int hmx_block_pre_fwd(const hmx_block_args* a, void* stream) {
     if (!fill_common(p, a)) return HMX_EINVAL;
     if (p.T == 0) return HMX_OK;
     if (!p.x || !p.scale1 || !p.b1 || !p.cs || !p.sn || !p.rstd1 || !p.x_in || !p.z || !p.y2) return HMX_EINVAL;
-    HMX_BLOCK_DISPATCH(block_pre_fwd_kernel, block_grid(p.T), (hipStream_t)stream, p);
+    HMX_BLOCK_DISPATCH(block_pre_fwd_kernel, p, (size_t)0, (size_t)0, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -814,7 +882,7 @@ extern "C" int hmx_block_post_fwd(const hmx_block_args* a, void* stream) {
     if (p.T == 0) return HMX_OK;
     if (!p.yg || !p.y2 || !p.x || !p.b2 || !p.scale2 || !p.out || !p.m || !p.rstd2 || (p.first && (!p.rstd1 || !p.scale1)))
         return HMX_EINVAL;
-    HMX_BLOCK_DISPATCH(block_post_fwd_kernel, block_grid(p.T), (hipStream_t)stream, p);
+    HMX_BLOCK_DISPATCH(block_post_fwd_kernel, p, (size_t)0, (size_t)0, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -827,7 +895,7 @@ extern "C" int hmx_block_post_bwd(const hmx_block_args* a, void* stream) {
     if (!p.dout || !p.m || !p.rstd2 || !p.scale2 || !p.yg || !p.y2 || !p.dyg || !p.dy2 || !p.dm || !p.hmid || !p.n2 || !p.dg ||
         !p.du || !p.p || !p.dy1 || !p.dscale_part)
         return HMX_EINVAL;
-    HMX_BLOCK_DISPATCH(block_post_bwd_kernel, block_grid(p.T), (hipStream_t)stream, p);
+    HMX_BLOCK_DISPATCH(block_post_bwd_kernel, p, p.lay.wg, p.lay.w2t + pack_entries(p.lay.d, p.lay.d), (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -840,7 +908,7 @@ extern "C" int hmx_block_pre_bwd(const hmx_block_args* a, void* stream) {
     if (!p.x || !p.scale1 || !p.b1 || !p.cs || !p.sn || !p.dx_in || !p.dz || !p.dy2 || !p.dm || !p.dx || !p.s || !p.dx1 || !p.n ||
         !p.dscale_part)
         return HMX_EINVAL;
-    HMX_BLOCK_DISPATCH(block_pre_bwd_kernel, block_grid(p.T), (hipStream_t)stream, p);
+    HMX_BLOCK_DISPATCH(block_pre_bwd_kernel, p, p.lay.w1, p.lay.wint + p.lay.wint_stride * p.lay.H, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
