@@ -329,16 +329,21 @@ __global__ __launch_bounds__(64, 2) void coarse_bf16_kernel(CoarseParams p) {
 // LDS rows are 128 B; the 16-byte chunk c of row r sits at chunk position c ^ (r & 7), which spreads the eight
 // rows read by neighbouring lanes over all banks without padding (the DMA needs a dense destination).
 constexpr int kRingWaves = 8;
-constexpr int kStageTiles = 4;
 constexpr int kStages = 8;
 constexpr int kLookahead = 5;
-constexpr int kStageBytes = kStageTiles * 32 * 128;
+constexpr int kStageBytes = 16 * 1024;   // a stage is 128 rows of 128 B (d = 64) or 64 rows of 256 B (d = 128)
 constexpr int kRingSpinLimit = 1 << 20;   // polls (s_sleep + LDS read, ~100 ns each) before a wait gives up
 constexpr int kRingAbort = 1 << 30;       // counter value that means "this workgroup has given up"
 
-template <int NB, int KP>
+template <int NB, int KP, int KS>
 __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(CoarseParams p) {
-    constexpr int KS = 4;
+    static_assert(KS == 4 || KS == 8, "row of 64 or 128 bf16");
+    constexpr int kRowBytes = 32 * KS;                // one bf16 row in LDS
+    constexpr int kTileBytes = 32 * kRowBytes;        // one 32-row tile
+    constexpr int kStageTiles = kStageBytes / kTileBytes;   // 4 (d = 64) or 2 (d = 128)
+    constexpr int kCpr = kRowBytes / 16;              // 16-byte chunks per row: 8 or 16
+    constexpr int kRowsPerDma = 1024 / kRowBytes;     // rows one DMA instruction (64 lanes x 16 B) covers: 8 or 4
+    constexpr int kDpad = 16 * KS;
     constexpr int CAP = cap_for(KP);
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     __shared__ int ready[kStages];   // generation (stage / kStages + 1) of the data in each slot
@@ -382,18 +387,21 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
     const int n_tiles = (n_rows_here + 31) / 32;
     const int n_stages = (n_tiles + kStageTiles - 1) / kStageTiles;
 
-    // This wave fetches a whole stage: 16 DMA instructions of 64 lanes x 16 B; instruction i covers rows 8i..8i+7
-    // of the stage and lands dense in LDS (lane order).  Lane l serves row 8i + (l >> 3) and writes chunk position
-    // l & 7, so it reads logical chunk (l & 7) ^ (l >> 3): per lane the source is one pointer plus i * 1024 B.
-    const int lrow = lane >> 3, lchunk = (lane & 7) ^ (lane >> 3);
+    // This wave fetches a whole stage: 16 DMA instructions of 64 lanes x 16 B; instruction i covers kRowsPerDma rows
+    // of the stage and lands dense in LDS (lane order).  Lane l serves row i * kRowsPerDma + l / kCpr and writes chunk
+    // position l % kCpr, so it reads logical chunk (l % kCpr) ^ (row % kCpr) -- kRowsPerDma divides kCpr, so that
+    // is (l % kCpr) ^ ((i * kRowsPerDma + l / kCpr) % kCpr); for d = 64 (8 rows per DMA = kCpr) it does not depend on i
+    // and the source is one pointer plus i * 1024 B per lane.
+    const int lrow = lane / kCpr, lpos = lane % kCpr;
     auto fetch_stage = [&](int s, bool clamp) {
         char* dst = smem + (s % kStages) * kStageBytes;
         const int64_t base_row = row_begin + (int64_t)s * (kStageTiles * 32) + lrow;
-        const uint16_t* src0 = p.t_bf16 + base_row * 64 + 8 * lchunk;
 #pragma unroll
         for (int i = 0; i < kStageBytes / 1024; ++i) {
-            const uint16_t* src = src0 + i * 512;
-            if (clamp) src = p.t_bf16 + min(base_row + 8 * i, row_end - 1) * 64 + 8 * lchunk;
+            const int lchunk = lpos ^ ((i * kRowsPerDma + lrow) % kCpr);
+            int64_t r = base_row + kRowsPerDma * i;
+            if (clamp) r = min(r, row_end - 1);
+            const uint16_t* src = p.t_bf16 + r * kDpad + 8 * lchunk;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
         }
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
         asm volatile("" ::: "memory");
         return v >= kRingAbort;
     };
-    const int n_full_stages = n_rows_here / (kStageTiles * 32);   // stages whose 128 rows all exist
+    const int n_full_stages = n_rows_here / (kStageTiles * 32);   // stages whose rows all exist
     int pending = -1;
     // what a wave does on entering stage c: its fetching duty for stage c + kLookahead, then wait for stage c
     auto enter_stage = [&](int c) -> bool {
@@ -448,13 +456,13 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the slot are complete
         if (lane == 0) __hip_atomic_fetch_add(&done[c % kStages], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    // A fragments of tile tl of a stage image: row tl * 32 + j, logical chunk 2 ks + h, swizzled by (row & 7) = (j & 7)
+    // A fragments of tile tl of a stage image: row tl * 32 + j, logical chunk 2 ks + h, swizzled by row % kCpr = j % kCpr
     int a_off[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a_off[ks] = j * 128 + 16 * ((2 * ks + h) ^ (j & 7));
+    for (int ks = 0; ks < KS; ++ks) a_off[ks] = j * kRowBytes + 16 * ((2 * ks + h) ^ (j % kCpr));
     auto read_tile = [&](short8(&a)[KS], const char* img, int tl) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const short8*>(img + tl * 4096 + a_off[ks]);
+        for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const short8*>(img + tl * kTileBytes + a_off[ks]);
     };
     auto compute_tile = [&](const short8(&a)[KS], int t, bool may_be_partial) {
         f32x16 acc[NB];
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
         fetch_stage(w, w >= n_full_stages);
         publish(w);
     }
-    // Full stages, four tiles each, software-pipelined inside the wave over two accumulator sets: while the MFMAs of
+    // Full stages, four tiles each (two for d = 128), software-pipelined inside the wave over two accumulator sets: while the MFMAs of
     // tile t fill one set, the filter walks the other set (tile t - 1), one query group per MFMA quarter, and the
     // fragment register a quarter has just consumed is reloaded with the next tile's.  The vector work of the
     // filter then issues in the shadow of the matrix pipe instead of after it.  The idle set starts at -inf, so
@@ -522,11 +530,15 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
 #ifdef HMX_RING_PRIO
             if ((c ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
-            step(accA, accB, img + 4096, t - 1);
-            step(accB, accA, img + 8192, t);
-            step(accA, accB, img + 12288, t + 1);
+            if constexpr (kStageTiles == 4) {
+                step(accA, accB, img + kTileBytes, t - 1);
+                step(accB, accA, img + 2 * kTileBytes, t);
+                step(accA, accB, img + 3 * kTileBytes, t + 1);
+            } else {
+                step(accA, accB, img + kTileBytes, t - 1);
+            }
             // fragments of this stage's last tile are in registers: retire the slot, take the next stage
-            const char* next = img + 12288;               // no next full stage: re-read this tile (unused)
+            const char* next = img + (kStageTiles - 1) * kTileBytes;   // no next full stage: re-read this tile (unused)
             if (c + 1 < n_full_stages) {
                 leave_stage(c);
                 if (enter_stage(c + 1)) {     // given up: the next stage is not there to be read
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
                 }
                 next = smem + ((c + 1) % kStages) * kStageBytes;
             }
-            step(accB, accA, next, t + 2);
+            step(accB, accA, next, t + kStageTiles - 2);
         }
         if (!aborted) {
             leave_stage(n_full_stages - 1);
@@ -1085,7 +1097,8 @@ int dpad_for(int64_t d) {
     return p;
 }
 
-// The shared-stream kernel exists for d = 64 (four 16-wide K steps) with four query groups per wave.
+// The shared-stream kernel exists for rows of 64 and of 128 bf16 (four or eight 16-wide K steps) with up to
+// 16 / KS query groups per wave.
 bool ring_enabled() {
     static const bool on = [] {
         const char* e = getenv("HMX_TOPK_RING");
@@ -1098,9 +1111,9 @@ bool ring_enabled() {
 // seeding passes) is left to the independent-wave kernel.
 constexpr int64_t kRingMinRowsFewQueries = 1 << 18;
 bool ring_shape(bool bf16, int NB, int KS, int64_t n_q) {
-    return bf16 && KS == 4 && ring_enabled() && (NB == 4 || n_q >= 512);
+    return bf16 && (KS == 4 || KS == 8) && ring_enabled() && (NB == 4 || (KS == 8 && NB == 2) || n_q >= 512);
 }
-bool ring_pass(int NB, int64_t rows) { return NB == 4 || rows >= kRingMinRowsFewQueries; }
+bool ring_pass(int NB, int KS, int64_t rows) { return NB == 4 || (KS == 8 && NB == 2) || rows >= kRingMinRowsFewQueries; }
 
 int g_debug_skip_publish = -1;   // see hmx_debug_ring_skip_publish
 
@@ -1135,13 +1148,13 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
 // re-scored, and the completeness proof there covers what they displaced.
 template <int NB, int KS, int KP>
 void launch_bf16(const CoarseParams& p, hipStream_t s) {
-    if constexpr (KS == 4) {
+    if constexpr ((KS == 4 || KS == 8) && NB * KS <= 16) {   // query fragments of a wave fit 64 registers
         if (ring_enabled() && p.n_qtiles % kRingWaves == 0 && p.ring_error != nullptr) {
             constexpr int lds = kStages * kStageBytes;
             static const hipError_t attr = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&coarse_bf16_ring_kernel<NB, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                reinterpret_cast<const void*>(&coarse_bf16_ring_kernel<NB, KP, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             (void)attr;
-            hipLaunchKernelGGL((coarse_bf16_ring_kernel<NB, KP>), dim3((p.n_qtiles / kRingWaves) * p.n_splits),
+            hipLaunchKernelGGL((coarse_bf16_ring_kernel<NB, KP, KS>), dim3((p.n_qtiles / kRingWaves) * p.n_splits),
                                dim3(64 * kRingWaves), lds, s, p);
             return;
         }
@@ -1315,7 +1328,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             p.n_excl = (int)n_excl;
             p.id_offset = id_offset;
             p.init_thr = thr0;
-            p.ring_error = (ring && ring_pass(plan.NB, rows)) ? ring_error : nullptr;
+            p.ring_error = (ring && ring_pass(plan.NB, plan.KS, rows)) ? ring_error : nullptr;
             p.debug_skip_publish = -1;
             if (p.ring_error != nullptr && rows == n_rows && g_debug_skip_publish >= 0) {   // one-shot test hook, full pass
                 p.debug_skip_publish = g_debug_skip_publish;
@@ -1360,7 +1373,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             r.out_ids = out_ids + q0 * k;
             r.out_scores = out_scores + q0 * k;
             r.uncertain = flags;
-            r.ring_error = (ring && ring_pass(plan.NB, rows)) ? ring_error : nullptr;
+            r.ring_error = (ring && ring_pass(plan.NB, plan.KS, rows)) ? ring_error : nullptr;
             launch_rescore(r, s);
             HMX_CHECK_LAUNCH();
             return HMX_OK;

@@ -1,0 +1,29 @@
+"""Scatter-add probe: n uniform random ids over a rows x d table (defaults: the benchmark's 16.8 M ids, 4 M x 64)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from generative_recommenders_amd import hmx, ops  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 24
+rows = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_001
+d = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(3)
+ids = torch.randint(1, rows, (n,), device=dev, generator=g)
+grad = torch.randn(n, d, device=dev, generator=g)
+out = torch.zeros(rows, d, device=dev)
+ops.scatter_add_rows(grad, ids, rows, 0, out=out)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    ops.scatter_add_rows(grad, ids, rows, 0, out=out)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / reps * 1e3
+u = int(torch.unique(ids).numel())
+alg = n * (8 + 4 * d) + 2 * u * 4 * d
+print(f"scatter_add n={n} rows={rows} d={d}: {ms:.3f} ms per call, unique {u}, algorithmic {alg / 1e9:.3f} GB -> {alg / ms / 1e9:.3f} TB/s "
+      f"({alg / ms / 1e9 / 8 * 100:.1f} % of 8 TB/s)")

@@ -95,12 +95,13 @@ def test_adversarial_near_duplicates_fall_back_to_exact():
     assert st["uncertain"] > 0
 
 
-def test_many_query_launch_with_planted_rows_and_near_duplicates():
+@pytest.mark.parametrize("d", [64, 128])
+def test_many_query_launch_with_planted_rows_and_near_duplicates(d):
     """The many-query launch shape (shared item stream, sampled start thresholds) on a table built to stress the
     start thresholds: every query's best rows are planted scaled copies placed outside and inside the sampled
     tiles, and a block of near-duplicate rows, larger than the two candidate lists of a query, tops query 0's scores."""
     g = torch.Generator().manual_seed(17)
-    nq, rows, d = 16400, 70_003, 64
+    nq, rows = 16400, 70_003
     t = torch.randn(rows, d, generator=g)
     q = torch.randn(nq, d, generator=g)
     spots = torch.randint(1, rows, (nq,), generator=g)
@@ -137,12 +138,15 @@ def test_shared_stream_give_up_ends_early_and_is_rerun_exactly():
     assert st2["uncertain"] == st0["uncertain"] and torch.equal(ids2, ids0)
 
 
-@pytest.mark.parametrize("nq,rows,k,with_excl", [(1024, 300_017, 50, True), (640, 262_144, 10, False),
-                                                 (4100, 270_001, 10, False), (4096, 262_200, 50, True)])
-def test_few_query_shared_stream_shapes(nq, rows, k, with_excl):
+@pytest.mark.parametrize("nq,rows,k,with_excl,d", [(1024, 300_017, 50, True, 64), (640, 262_144, 10, False, 64),
+                                                   (4100, 270_001, 10, False, 64), (4096, 262_200, 50, True, 64),
+                                                   (1024, 300_017, 50, True, 128), (600, 262_208, 10, False, 128),
+                                                   (4100, 100_001, 10, False, 128), (8200, 70_070, 50, True, 100)])
+def test_few_query_shared_stream_shapes(nq, rows, k, with_excl, d):
     """Few queries over a long table (the hard-negative miner's shape): workgroups of eight waves with one or two
-    query groups per wave share the item stream, after the seeding passes over the table prefixes."""
-    q, t = _data(nq, rows, 64, 300 + nq)
+    query groups per wave share the item stream, after the seeding passes over the table prefixes.  Rows of 128
+    bf16 (d = 128, and d = 100 padded to it) take the two-tile stages of the same kernel."""
+    q, t = _data(nq, rows, d, 300 + nq)
     excl = None
     if with_excl:
         g = torch.Generator().manual_seed(31)
