@@ -2,7 +2,7 @@
 //
 // out[key] += sum over the entries carrying that key of value(entry), where value(entry) is produced by a
 // source functor (a materialised row, or coefficient x row).  The entries are sorted by key with a stable radix
-// sort, so within a key they stay in entry order; see segment_sum_kernel for the fixed association order.
+// sort, so within a key they stay in entry order; see segment_sum_staged_kernel for the fixed association order.
 #pragma once
 #include <algorithm>
 #include <cstring>
@@ -11,10 +11,6 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "hmx_common.h"
-
-#ifndef HMX_PLAIN_IN_FLIGHT
-#define HMX_PLAIN_IN_FLIGHT 16
-#endif
 
 namespace hmx_seg {
 namespace {   // internal linkage: every translation unit that includes this header gets its own kernels
@@ -43,15 +39,11 @@ __device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
 // value(entry) = rows[entry]: the plain scatter-add of materialised gradient rows
 struct PlainRows {
     using Val = uint32_t;               // what travels with the key through the sort: the entry number
-    static constexpr int kInFlight = HMX_PLAIN_IN_FLIGHT; // entries requested per trip of the run loop (summed in order)
-    static constexpr int kPiece = 512;  // the sorted array is also cut every kPiece entries
-    static constexpr bool kBalanced = false;   // one group per run start (summation order fixed by the contract)
     const float* rows;
     __device__ __forceinline__ Val make_val(int64_t e) const { return (uint32_t)e; }
-    template <int VEC>
-    __device__ __forceinline__ typename VecT<VEC>::type load(Val pos, int cpr, int c) const {
-        return reinterpret_cast<const typename VecT<VEC>::type*>(rows)[(int64_t)pos * cpr + c];
-    }
+    __device__ __forceinline__ int64_t row_index(Val v) const { return (int64_t)v; }
+    template <class V>
+    __device__ __forceinline__ V weigh(Val, const V& v) const { return v; }
 };
 
 __device__ __forceinline__ float4 vscale(float a, const float4& v) { return make_float4(a * v.x, a * v.y, a * v.z, a * v.w); }
@@ -63,9 +55,6 @@ struct WeightedRows {
     // The coefficient rides through the sort next to the source row number, so the run loop reads it from the
     // sorted stream instead of chasing a random 4-byte load per entry.
     using Val = uint2;                  // (source row i, coefficient bits)
-    static constexpr int kInFlight = 8;
-    static constexpr int kPiece = 128;
-    static constexpr bool kBalanced = true;    // one group per block of kPiece entries (runs here are long)
     const float* rows;      // (n_src, d)
     const float* coef;      // (n_src, coef_stride)
     int per_row, coef_stride, col0;
@@ -73,11 +62,9 @@ struct WeightedRows {
         const int64_t i = e / per_row, sidx = e - i * per_row;
         return make_uint2((uint32_t)i, __float_as_uint(coef[i * coef_stride + col0 + sidx]));
     }
-    template <int VEC>
-    __device__ __forceinline__ typename VecT<VEC>::type load(Val v, int cpr, int c) const {
-        return vscale(__uint_as_float(v.y),
-                      reinterpret_cast<const typename VecT<VEC>::type*>(rows)[(int64_t)v.x * cpr + c]);
-    }
+    __device__ __forceinline__ int64_t row_index(Val v) const { return (int64_t)v.x; }
+    template <class V>
+    __device__ __forceinline__ V weigh(Val sv, const V& v) const { return vscale(__uint_as_float(sv.y), v); }
 };
 
 inline int lpr_log2_for(int64_t cpr) {
@@ -103,195 +90,205 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(Src src, const int64_
     }
 }
 
-// Step 3 (pass 1): the sorted array is cut at every change of id AND at every multiple of kSuper
-// entries into "pieces"; one group of LPR lanes sums one piece sequentially in sorted (= original, the
-// sort is stable) order.  A group owns the pieces whose first entry lies in its chunk of kChunk entries.
+// Step 3 (pass 1): the sorted array is cut at every change of id AND at every multiple of kSuper entries into
+// "pieces"; a piece is summed sequentially in sorted (= original, the sort is stable) order, starting from zero.
 //   piece == whole run            -> added to the table row (exactly one writer per row)
-//   piece continues an older run  -> head_piece[super-block]   (it starts at the block's first entry)
-//   piece starts a run that goes on past the block end -> tail_piece[super-block]
+//   piece continues an older run  -> head_piece[block]   (it starts at the block's first entry)
+//   piece starts a run that goes on past the block end -> tail_piece[block]
 // Pass 2: the group of the block where such a run starts adds tail_piece[b] + head_piece[b+1] + ... in
 // block order and writes the row.  The association order depends only on positions in the sorted array,
 // never on timing, so the result is bitwise reproducible; no float atomics; the sequential depth is
 // bounded by kSuper whatever the id skew.
-constexpr int kChunk = 8;
+//
+// One workgroup owns one block of kSuper sorted entries.  Its keys and values are read once into LDS; the
+// wave ballots of "differs from the entry before" give every piece its number and extent (one entry in the
+// list per distinct row of the block).  The source rows -- a random 4 * d bytes each, the bulk of the traffic --
+// come in through the LDS DMA path in sub-blocks of S entries, double-buffered: while the groups of lpr lanes
+// walk the pieces of sub-block k out of LDS, the rows of sub-block k + 1 are in flight, 32 KB per workgroup and no
+// registers held.  A piece that crosses a sub-block boundary hands its running sum to the next sub-block through
+// a carry row, so its additions still happen one after the other in entry order.
 constexpr int kSuper = 512;
+constexpr int kStageBytes = 32 * 1024;
 
-// WIDE: trips of Src::kInFlight entries with all keys requested up front, for inputs whose runs are long (a small
-// table hit by many ids: the trip is three dependent memory latencies deep, so depth is what counts); otherwise
-// trips of four with the key loads stopping at the run's end, which costs the least registers and loads when
-// most runs are one or two entries long.  The additions happen in entry order either way: same bits.
-template <int VEC, class Src, bool WIDE>
-__global__ __launch_bounds__(kBlock) void segment_sum_kernel(Src src,
-                                                             const uint32_t* __restrict__ skeys,
-                                                             const typename Src::Val* __restrict__ svals, int64_t n, int cpr,
-                                                             int lpr_log2, uint32_t sentinel,
-                                                             float* __restrict__ grad_table,
-                                                             float* __restrict__ head_piece,
-                                                             float* __restrict__ tail_piece) {
+template <int VEC, class Src>
+__global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, const uint32_t* __restrict__ skeys,
+                                                                    const typename Src::Val* __restrict__ svals,
+                                                                    int64_t n, int cpr, int lpr_log2, int S,
+                                                                    int stage_bytes, uint32_t sentinel,
+                                                                    float* __restrict__ grad_table,
+                                                                    float* __restrict__ head_piece,
+                                                                    float* __restrict__ tail_piece) {
     using V = typename VecT<VEC>::type;
-    const int lpr = 1 << lpr_log2;
-    const int lane_c = threadIdx.x & (lpr - 1);
-    const int groups_per_block = kBlock >> lpr_log2;
-    const int64_t n_groups = (n + kChunk - 1) / kChunk;
-    for (int64_t g = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> lpr_log2); g < n_groups;
-         g += (int64_t)gridDim.x * groups_per_block) {
-        const int64_t j0 = g * kChunk;
-        const int64_t j1 = (j0 + kChunk < n) ? j0 + kChunk : n;
-        const int64_t sb = j0 / kSuper;                       // kSuper is a multiple of kChunk
-        const int64_t blk_end = ((sb + 1) * kSuper < n) ? (sb + 1) * kSuper : n;
-        uint32_t prev = (j0 == 0) ? sentinel : skeys[j0 - 1];
-        for (int64_t j = j0; j < j1; ++j) {
-            const uint32_t key = skeys[j];
-            if (key == sentinel) break;          // sentinels sort last: nothing further in this chunk
-            const bool starts_true = (j == 0) || key != prev;
-            const bool head = starts_true || (j % kSuper == 0);
-            prev = key;
-            if (!head) continue;
-            // extent of the piece: [j, e_end)
-            int64_t e_end = j;
-            for (int c = lane_c; c < cpr; c += lpr) {
-                V acc = vzero<VEC>();
-                int64_t e = j;
-                auto trip = [&](auto width) -> bool {
-                    constexpr int U = decltype(width)::value;
-                    bool m[U];
-                    typename Src::Val sv[U];
-                    V v[U];
-                    bool run = true;
-                    if constexpr (WIDE) {
-                        uint32_t kk[U];
+    using Val = typename Src::Val;
+    constexpr int CH = VEC * 4;               // bytes per lane per DMA instruction
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // two stages, then two carry rows
+    __shared__ uint32_t keyL[kSuper + 1];     // [nb] holds the key after the block
+    __shared__ Val valL[kSuper];
+    __shared__ int piece_start[kSuper + 1];
+    __shared__ int sub_first[kSuper + 1];     // first piece of each sub-block
+    __shared__ int wave_cnt[2][kBlock / 64], wave_valid[2][kBlock / 64];
+    __shared__ int carry_flag[2];             // "the carried piece began at a true run start"
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t sb = blockIdx.x;
+    const int64_t j0 = sb * kSuper;
+    if (skeys[j0] == sentinel) return;        // sentinels sort last: nothing in this block contributes
+    const int nb = (int)((n - j0 < kSuper) ? n - j0 : kSuper);
+    for (int i = tid; i < nb; i += kBlock) {
+        keyL[i] = skeys[j0 + i];
+        valL[i] = svals[j0 + i];
+    }
+    if (tid == 0) keyL[nb] = (j0 + nb < n) ? skeys[j0 + nb] : sentinel;
+    const uint32_t key_before = (j0 > 0) ? skeys[j0 - 1] : sentinel;
+    __syncthreads();
+
+    // piece list: an entry starts a piece when its key differs from the entry before it, or when it is the first
+    // of a sub-block (so that no piece spans two stages; the carry row joins the halves again)
+    bool my_start[2];
+    int my_rank[2];
 #pragma unroll
-                        for (int u = 0; u < U; ++u) kk[u] = skeys[(e + u < blk_end) ? e + u : blk_end - 1];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            run = run && (e + u < blk_end) && (kk[u] == key);
-                            m[u] = run;
-                        }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            run = run && (e + u < blk_end) && (skeys[e + u] == key);
-                            m[u] = run;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (m[u]) sv[u] = svals[e + u];
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        v[u] = m[u] ? src.template load<VEC>(sv[u], cpr, c) : vzero<VEC>();
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (m[u]) {
-                            vadd(acc, v[u]);
-                            e_end = e + u + 1;
-                        }
-                    if (!m[U - 1]) return false;
-                    e += U;
-                    return true;
-                };
-                if constexpr (WIDE) {
-                    while (trip(std::integral_constant<int, Src::kInFlight>{})) {
-                    }
-                } else {
-                    while (trip(std::integral_constant<int, 4>{})) {
-                    }
-                }
-                {
-                    const bool ends_true = (e_end == n) || skeys[e_end] != key;
-                    V* dst;
-                    bool add;
-                    if (starts_true && ends_true) {
-                        dst = reinterpret_cast<V*>(grad_table) + (int64_t)key * cpr + c;
-                        add = true;
-                    } else if (!starts_true) {
-                        dst = reinterpret_cast<V*>(head_piece) + sb * cpr + c;
-                        add = false;
-                    } else {
-                        dst = reinterpret_cast<V*>(tail_piece) + sb * cpr + c;
-                        add = false;
-                    }
-                    if (add) {
-                        V cur = *dst;
-                        vadd(cur, acc);
-                        *dst = cur;
-                    } else {
-                        *dst = acc;
-                    }
-                }
-            }
+    for (int r = 0; r < 2; ++r) {
+        const int i = r * kBlock + tid;
+        const bool valid = i < nb && keyL[i] != sentinel;
+        const bool start = valid && (i % S == 0 || keyL[i] != keyL[i - 1]);
+        const unsigned long long bs = __ballot(start), bv = __ballot(valid);
+        my_start[r] = start;
+        my_rank[r] = __popcll(bs & ((1ull << lane) - 1ull));
+        if (lane == 0) {
+            wave_cnt[r][w] = __popcll(bs);
+            wave_valid[r][w] = __popcll(bv);
         }
     }
-}
-
-// Pass 1, balanced form: one group walks one block of SB consecutive sorted entries, whatever runs it holds, so
-// every group has the same amount of work and long runs are summed by many groups at once.  Partial sums of runs
-// that cross a block boundary go to head_piece / tail_piece exactly as in segment_sum_kernel (with kSuper = SB);
-// runs that lie inside one block are added to their row directly (one writer per row).
-template <int VEC, class Src, int SB>
-__global__ __launch_bounds__(kBlock) void segment_sum_balanced_kernel(Src src, const uint32_t* __restrict__ skeys,
-                                                                      const typename Src::Val* __restrict__ svals,
-                                                                      int64_t n, int cpr, int lpr_log2,
-                                                                      uint32_t sentinel, float* __restrict__ grad_table,
-                                                                      float* __restrict__ head_piece,
-                                                                      float* __restrict__ tail_piece) {
-    using V = typename VecT<VEC>::type;
-    constexpr int U = Src::kInFlight;
-    static_assert(SB % U == 0, "block size must be a multiple of the prefetch depth");
-    const int lpr = 1 << lpr_log2;
-    const int lane_c = threadIdx.x & (lpr - 1);
-    const int groups_per_block = kBlock >> lpr_log2;
-    const int64_t n_sb = (n + SB - 1) / SB;
-    for (int64_t b = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> lpr_log2); b < n_sb;
-         b += (int64_t)gridDim.x * groups_per_block) {
-        const int64_t j0 = b * SB;
-        const int64_t j1 = (j0 + SB < n) ? j0 + SB : n;
-        const uint32_t key_before = (j0 > 0) ? skeys[j0 - 1] : sentinel;
-        const uint32_t key_after = (j1 < n) ? skeys[j1] : sentinel;
-        for (int c = lane_c; c < cpr; c += lpr) {
-            V acc = vzero<VEC>();
-            uint32_t cur = skeys[j0];
-            bool first_run = true;   // the run being summed began at j0 (it may continue an older block's run)
-            auto flush = [&](bool ends_here) {
-                if (cur == sentinel) return;
-                const bool starts_true = !(first_run && cur == key_before);
-                V* dst;
-                if (starts_true && ends_here) {
-                    dst = reinterpret_cast<V*>(grad_table) + (int64_t)cur * cpr + c;
-                    V t = *dst;
-                    vadd(t, acc);
-                    *dst = t;
-                } else if (!starts_true) {
-                    reinterpret_cast<V*>(head_piece)[b * cpr + c] = acc;
-                } else {
-                    reinterpret_cast<V*>(tail_piece)[b * cpr + c] = acc;
-                }
-            };
-            for (int64_t e = j0; e < j1; e += U) {
-                uint32_t key[U];
-                typename Src::Val sv[U];
-                V v[U];
+    __syncthreads();
+    int n_pieces = 0, n_valid = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) key[u] = (e + u < j1) ? skeys[e + u] : sentinel;
+    for (int r = 0; r < 2; ++r) {
+        int base = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (key[u] != sentinel) sv[u] = svals[e + u];
+        for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    v[u] = (key[u] != sentinel) ? src.template load<VEC>(sv[u], cpr, c) : vzero<VEC>();
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (e + u >= j1) break;
-                    if (key[u] != cur) {
-                        flush(true);
-                        acc = vzero<VEC>();
-                        cur = key[u];
-                        first_run = false;
-                    }
-                    if (key[u] != sentinel) vadd(acc, v[u]);
+            for (int w2 = 0; w2 < kBlock / 64; ++w2) {
+                if (r2 < r || (r2 == r && w2 < w)) base += wave_cnt[r2][w2];
+                if (r == 0) {
+                    n_pieces += wave_cnt[r2][w2];
+                    n_valid += wave_valid[r2][w2];
                 }
             }
-            flush(cur != key_after);
+        if (my_start[r]) {
+            const int i = r * kBlock + tid;
+            piece_start[base + my_rank[r]] = i;
+            if (i % S == 0) sub_first[i / S] = base + my_rank[r];
+        }
+    }
+    const int n_sub = (n_valid + S - 1) / S;
+    if (tid == 0) {
+        piece_start[n_pieces] = n_valid;
+        sub_first[n_sub] = n_pieces;
+    }
+    __syncthreads();
+
+    // DMA of one sub-block: flat 16-byte (4-byte when rows are not 16-byte multiples) chunk f of the stage is chunk
+    // f % cpr of entry f / cpr; a wave's instruction covers 64 consecutive chunks and lands them dense in LDS.
+    const int q0 = tid / cpr, r0 = tid % cpr, step_q = kBlock / cpr, step_r = kBlock % cpr;
+    auto issue = [&](int k) {
+        char* st = smem + (k & 1) * stage_bytes;
+        const int e0 = k * S;
+        const int cnt = (n_valid - e0 < S) ? n_valid - e0 : S;
+        const int total = cnt * cpr;
+        int q = q0, r = r0;
+        for (int f0 = 0; f0 < total; f0 += kBlock) {
+            if (f0 + tid < total) {
+                const char* g = reinterpret_cast<const char*>(src.rows) + (src.row_index(valL[e0 + q]) * cpr + r) * CH;
+                auto* gp = (const __attribute__((address_space(1))) void*)g;
+                auto* lp = (__attribute__((address_space(3))) void*)(st + (f0 + w * 64) * CH);
+                if constexpr (VEC == 4) __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+                else __builtin_amdgcn_global_load_lds(gp, lp, 4, 0, 0);
+            }
+            r += step_r;
+            q += step_q;
+            if (r >= cpr) {
+                r -= cpr;
+                ++q;
+            }
+        }
+    };
+
+    const int lpr = 1 << lpr_log2;
+    const int lane_c = tid & (lpr - 1), grp = tid >> lpr_log2, n_groups = kBlock >> lpr_log2;
+    V* carry = reinterpret_cast<V*>(smem + 2 * stage_bytes);   // [2][cpr]
+    issue(0);
+    for (int k = 0; k < n_sub; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of sub-block k is in LDS
+        __syncthreads();                                    // everyone's is, and sub-block k - 1 has been consumed
+        const V* st = reinterpret_cast<const V*>(smem + (k & 1) * stage_bytes);
+        const int e0 = k * S;
+        // U pieces per trip: their table rows are requested first (and before the next stage's DMA, which would
+        // otherwise queue ahead of them), then each piece is summed out of LDS while those reads are in flight.
+        constexpr int U = 4;
+        const int p_end = sub_first[k + 1];
+        bool dma_issued = false;
+        for (int p0 = sub_first[k] + grp; p0 < p_end || !dma_issued; p0 += n_groups * U) {
+            int s_pos[U], e_pos[U];
+            uint32_t key[U];
+            bool live[U], continues[U], goes_on[U], starts_true[U], whole[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = p0 + u * n_groups;
+                live[u] = p < p_end;
+                s_pos[u] = live[u] ? piece_start[p] : 0;
+                e_pos[u] = live[u] ? piece_start[p + 1] : 0;
+                key[u] = keyL[s_pos[u]];
+                continues[u] = s_pos[u] == e0 && k > 0 && keyL[s_pos[u] > 0 ? s_pos[u] - 1 : 0] == key[u];   // other half: carry row
+                goes_on[u] = e_pos[u] == e0 + S && e_pos[u] < n_valid && keyL[e_pos[u]] == key[u];
+                starts_true[u] = continues[u] ? (carry_flag[(k - 1) & 1] != 0) : (s_pos[u] > 0 || key_before != key[u]);
+                whole[u] = live[u] && !goes_on[u] && starts_true[u] && keyL[e_pos[u]] != key[u];
+            }
+            for (int c = lane_c; c < cpr; c += lpr) {
+                V cur[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    cur[u] = vzero<VEC>();
+                    if (whole[u]) cur[u] = (reinterpret_cast<const V*>(grad_table) + (int64_t)key[u] * cpr)[c];
+                }
+                asm volatile("" ::: "memory");
+                if (!dma_issued && c == lane_c) {          // wave-uniform: every wave passes here exactly once per stage
+                    if (k + 1 < n_sub) issue(k + 1);
+                    dma_issued = true;
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!live[u]) continue;
+                    V acc = continues[u] ? carry[((k - 1) & 1) * cpr + c] : vzero<VEC>();
+                    const V* rowp = st + (s_pos[u] - e0) * cpr + c;
+                    int e = s_pos[u];
+                    for (; e + 4 <= e_pos[u]; e += 4, rowp += 4 * cpr) {
+                        const V v0 = rowp[0], v1 = rowp[cpr], v2 = rowp[2 * cpr], v3 = rowp[3 * cpr];
+                        vadd(acc, src.weigh(valL[e], v0));
+                        vadd(acc, src.weigh(valL[e + 1], v1));
+                        vadd(acc, src.weigh(valL[e + 2], v2));
+                        vadd(acc, src.weigh(valL[e + 3], v3));
+                    }
+                    for (; e < e_pos[u]; ++e, rowp += cpr) vadd(acc, src.weigh(valL[e], rowp[0]));
+                    if (goes_on[u]) {
+                        carry[(k & 1) * cpr + c] = acc;
+                    } else if (whole[u]) {
+                        vadd(cur[u], acc);
+                        (reinterpret_cast<V*>(grad_table) + (int64_t)key[u] * cpr)[c] = cur[u];
+                    } else if (!starts_true[u]) {
+                        reinterpret_cast<V*>(head_piece)[sb * cpr + c] = acc;
+                    } else {
+                        reinterpret_cast<V*>(tail_piece)[sb * cpr + c] = acc;
+                    }
+                }
+            }
+            if (!dma_issued) {                             // lanes beyond the row width (lane_c >= cpr) never enter the c loop
+                if (k + 1 < n_sub) issue(k + 1);
+                dma_issued = true;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (live[u] && goes_on[u] && lane_c == 0) carry_flag[k & 1] = starts_true[u] ? 1 : 0;
         }
     }
 }
@@ -362,6 +359,9 @@ inline size_t rocprim_sort_temp_bytes(int64_t n, int bits) {
 }
 
 
+constexpr int kMaxRowFloats = kStageBytes / 4;      // one row must fit an LDS stage
+constexpr int kMaxStagedLds = 2 * kStageBytes + 2 * kStageBytes;   // two stages + two carry rows at the widest row
+
 inline size_t piece_bytes(int64_t n, int64_t d, int piece) {
     return hmx_align_up((size_t)hmx_ceil_div(n, piece) * (size_t)d * sizeof(float), 256);
 }
@@ -371,7 +371,7 @@ inline size_t workspace_bytes(int64_t n, int64_t n_rows, int64_t d) {
     if (n <= 0 || n_rows <= 0 || d <= 0) return 256;
     const size_t karr = hmx_align_up((size_t)n * sizeof(uint32_t), 256);
     const size_t varr = hmx_align_up((size_t)n * sizeof(typename Src::Val), 256);
-    return 2 * karr + 2 * varr + 2 * piece_bytes(n, d, Src::kPiece) +
+    return 2 * karr + 2 * varr + 2 * piece_bytes(n, d, kSuper) +
            hmx_align_up(rocprim_sort_temp_bytes<typename Src::Val>(n, sort_bits(n_rows)), 256) + 256;
 }
 
@@ -383,6 +383,7 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
                        int64_t n, int64_t d, float* table, int64_t n_rows, int64_t padding_idx, void* workspace,
                        size_t ws_bytes, hipStream_t s, const uint32_t** sorted_keys_out = nullptr,
                        uint32_t* sentinel_out = nullptr) {
+    if (d > kMaxRowFloats) return HMX_EINVAL;
     const int bits = sort_bits(n_rows);
     using Val = typename Src::Val;
     size_t temp_bytes = rocprim_sort_temp_bytes<Val>(n, bits);
@@ -392,8 +393,8 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
     Val* vals = ws.take<Val>(n);
     uint32_t* skeys = ws.take<uint32_t>(n);
     Val* svals = ws.take<Val>(n);
-    float* head_piece = ws.take<float>(piece_bytes(n, d, Src::kPiece) / sizeof(float));
-    float* tail_piece = ws.take<float>(piece_bytes(n, d, Src::kPiece) / sizeof(float));
+    float* head_piece = ws.take<float>(piece_bytes(n, d, kSuper) / sizeof(float));
+    float* tail_piece = ws.take<float>(piece_bytes(n, d, kSuper) / sizeof(float));
     void* temp = ws.take<char>(temp_bytes);
     const uint32_t sentinel = (uint32_t)n_rows;
     if (sorted_keys_out) *sorted_keys_out = skeys;
@@ -409,37 +410,32 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
 
     const int64_t cpr = vec ? d / 4 : d;
     const int l2 = lpr_log2_for(cpr);
-    constexpr int SB = Src::kPiece;
-    const int64_t n_sb = hmx_ceil_div(n, SB);
-    const int64_t groups = Src::kBalanced ? n_sb : hmx_ceil_div(n, kChunk);
-    const int grid3 = (int)std::min<int64_t>(hmx_ceil_div(groups, kBlock >> l2), (int64_t)kMaxGrid * 4);
+    const int64_t n_sb = hmx_ceil_div(n, kSuper);
+    const int row_bytes = (int)d * 4;
+    static const int stage_cap = [] {
+        const char* e = getenv("HMX_SEG_STAGE_KB");
+        const int kb = e ? atoi(e) : 0;
+        return (kb >= 1 && kb * 1024 <= kStageBytes) ? kb * 1024 : kStageBytes;
+    }();
+    const int S = std::max(1, std::min(kBlock, std::max(stage_cap, row_bytes) / row_bytes));   // entries per LDS stage
+    const int stage_bytes = (int)hmx_align_up((size_t)S * row_bytes, 1024);
+    const int lds = 2 * stage_bytes + 2 * (int)hmx_align_up((size_t)row_bytes, 16);
     const int grid4 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid);
-    const bool long_runs = n >= 8 * n_rows;   // on average eight or more entries per table row
     if (vec) {
-        if constexpr (Src::kBalanced)
-            hipLaunchKernelGGL((segment_sum_balanced_kernel<4, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys,
-                               svals, n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
-        else
-            if (long_runs)
-                hipLaunchKernelGGL((segment_sum_kernel<4, Src, true>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
-                                   n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
-            else
-                hipLaunchKernelGGL((segment_sum_kernel<4, Src, false>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
-                                   n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
-        hipLaunchKernelGGL((segment_join_kernel<4, SB>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&segment_sum_staged_kernel<4, Src>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedLds);
+        (void)attr;
+        hipLaunchKernelGGL((segment_sum_staged_kernel<4, Src>), dim3((unsigned)n_sb), dim3(kBlock), lds, s, src, skeys, svals,
+                           n, (int)cpr, l2, S, stage_bytes, sentinel, table, head_piece, tail_piece);
+        hipLaunchKernelGGL((segment_join_kernel<4, kSuper>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
                            sentinel, table, head_piece, tail_piece);
     } else {
-        if constexpr (Src::kBalanced)
-            hipLaunchKernelGGL((segment_sum_balanced_kernel<1, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys,
-                               svals, n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
-        else
-            if (long_runs)
-                hipLaunchKernelGGL((segment_sum_kernel<1, Src, true>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
-                                   n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
-            else
-                hipLaunchKernelGGL((segment_sum_kernel<1, Src, false>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
-                                   n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
-        hipLaunchKernelGGL((segment_join_kernel<1, SB>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&segment_sum_staged_kernel<1, Src>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedLds);
+        (void)attr;
+        hipLaunchKernelGGL((segment_sum_staged_kernel<1, Src>), dim3((unsigned)n_sb), dim3(kBlock), lds, s, src, skeys, svals,
+                           n, (int)cpr, l2, S, stage_bytes, sentinel, table, head_piece, tail_piece);
+        hipLaunchKernelGGL((segment_join_kernel<1, kSuper>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
                            sentinel, table, head_piece, tail_piece);
     }
     HMX_CHECK_LAUNCH();

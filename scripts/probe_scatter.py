@@ -4,7 +4,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from generative_recommenders_amd import hmx, ops  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 24
