@@ -1,0 +1,267 @@
+// Stable least-significant-digit radix sort of (uint32 key, value) entries for the sorted-run scatter-add.
+//
+// The keys are table row numbers (or a sentinel that sorts last), so only sort_bits(n_rows) bits are significant;
+// they are cut into ceil(bits / 8) digits of equal width.  A pass is: per-tile digit histograms, an exclusive scan
+// of every digit's row of tile counts, and a scatter that ranks the entries of a tile in index order (wave ballots
+// match equal digits; one LDS counter per wave and digit, no atomics on the ranking path) and moves them through
+// LDS so that neighbouring lanes write neighbouring addresses.  Entries with equal keys therefore keep their
+// original order through every pass, which is what fixes the summation order of the scatter-add.
+//
+// The first pass takes its keys and values from functors, so the ids are turned into keys on the fly and no
+// unsorted (key, value) arrays are ever written.  Launches of up to kSelfPrefixTiles tiles need no scan kernel:
+// each tile sums the few histograms before it by itself (two launches per pass).
+#pragma once
+#include <cstdint>
+
+#include "hmx_common.h"
+
+namespace hmx_sort {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kIpt = 16;                       // entries per thread
+constexpr int kTile = kThreads * kIpt;         // entries per workgroup
+constexpr int kDigits = 256;                   // counters per tile (digits narrower than 8 bits use a prefix of them)
+constexpr int kSelfPrefixTiles = 64;
+
+struct Passes {
+    int n;
+    int shift[4], bits[4];
+};
+inline Passes plan_passes(int key_bits) {
+    Passes p{};
+    p.n = (key_bits + 7) / 8;
+    if (p.n < 1) p.n = 1;
+    int at = 0;
+    for (int i = 0; i < p.n; ++i) {
+        const int left = key_bits - at, passes_left = p.n - i;
+        p.bits[i] = (left + passes_left - 1) / passes_left;
+        if (p.bits[i] < 1) p.bits[i] = 1;
+        p.shift[i] = at;
+        at += p.bits[i];
+    }
+    return p;
+}
+
+inline int64_t n_tiles_for(int64_t n) { return hmx_ceil_div(n, kTile); }
+// histogram rows (one per digit, n_tiles counters each) + the digit totals
+inline size_t counter_bytes(int64_t n) { return hmx_align_up(((size_t)kDigits * n_tiles_for(n) + kDigits) * sizeof(uint32_t), 256); }
+
+template <class Val>
+struct FromArrays {
+    const uint32_t* keys;
+    const Val* vals;
+    __device__ __forceinline__ uint32_t key(int64_t i) const { return keys[i]; }
+    __device__ __forceinline__ Val val(int64_t i) const { return vals[i]; }
+};
+
+template <class In>
+__global__ __launch_bounds__(kThreads) void radix_hist_kernel(In in, int64_t n, int shift, uint32_t mask, int n_tiles,
+                                                              uint32_t* __restrict__ hist) {
+    __shared__ unsigned h[kDigits];
+    const int tid = threadIdx.x, lane = tid & 63;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kTile;
+#pragma unroll 4
+    for (int r = 0; r < kIpt; ++r) {
+        const int64_t i = base + r * kThreads + tid;
+        const bool valid = i < n;
+        const uint32_t d = valid ? ((in.key(i) >> shift) & mask) : 0;
+        // one LDS atomic per distinct digit of the wave: lanes holding the same digit elect their lowest lane
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1);
+            m &= ((d >> b) & 1) ? bb : ~bb;
+        }
+        if (valid && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[d], (unsigned)__popcll(m));
+    }
+    __syncthreads();
+    hist[(int64_t)tid * n_tiles + blockIdx.x] = h[tid];
+}
+
+// exclusive prefix sum over the kThreads values of a workgroup; *total receives their sum
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_sums /* [kWaves] in LDS */, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_sums[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) {
+        const uint32_t s = wave_sums[i];
+        if (i < w) base += s;
+        all += s;
+    }
+    __syncthreads();          // wave_sums may be reused by the caller
+    *total = all;
+    return base + incl - v;
+}
+
+// one workgroup per digit: its row of tile counts becomes the row of exclusive prefixes; totals[digit] = the sum
+__global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restrict__ hist, int n_tiles,
+                                                              uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wave_sums[kWaves];
+    uint32_t* row = hist + (int64_t)blockIdx.x * n_tiles;
+    const int tid = threadIdx.x;
+    const int per = (n_tiles + kThreads - 1) / kThreads;
+    const int lo = min(tid * per, n_tiles), hi = min(lo + per, n_tiles);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += row[i];
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, wave_sums, &total);
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (tid == 0) totals[blockIdx.x] = total;
+}
+
+template <class In, class Val>
+__global__ __launch_bounds__(kThreads) void radix_scatter_kernel(In in, int64_t n, int shift, uint32_t mask, int n_tiles,
+                                                                 const uint32_t* __restrict__ hist,
+                                                                 const uint32_t* __restrict__ totals, int self_prefix,
+                                                                 uint32_t* __restrict__ out_keys, Val* __restrict__ out_vals) {
+    __shared__ uint32_t cnt[kWaves][kDigits];   // per wave and digit: running count, then the wave's base inside the digit
+    __shared__ uint32_t lstart[kDigits];        // where the digit starts in the tile's sorted order
+    __shared__ uint32_t goff[kDigits];          // global position of the digit's first entry of this tile, minus lstart
+    __shared__ uint32_t wave_sums[kWaves];
+    __shared__ uint32_t skey[kTile];
+    __shared__ Val sval[kTile];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) cnt[i][tid] = 0;
+    __syncthreads();
+
+    // wave w owns entries [w * 64 * kIpt, (w + 1) * 64 * kIpt) of the tile, 64 consecutive ones per round
+    const int64_t wbase = (int64_t)tile * kTile + (int64_t)w * 64 * kIpt;
+    uint32_t key[kIpt], rank[kIpt];
+    Val val[kIpt];
+#pragma unroll
+    for (int r = 0; r < kIpt; ++r) {
+        const int64_t i = wbase + r * 64 + lane;
+        if (i < n) {
+            key[r] = in.key(i);
+            val[r] = in.val(i);
+        }
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kIpt; ++r) {
+        const bool valid = wbase + r * 64 + lane < n;
+        const uint32_t d = valid ? ((key[r] >> shift) & mask) : 0;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1);
+            m &= ((d >> b) & 1) ? bb : ~bb;
+        }
+        const uint32_t before = __popcll(m & lt);
+        uint32_t old = 0;
+        if (valid) old = cnt[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) cnt[w][d] = old + (uint32_t)__popcll(m);   // the digit's lowest lane writes for all
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = old + before;
+    }
+    __syncthreads();
+
+    {   // thread d: this tile's count of digit d, the waves' bases inside it, and the digit's global position
+        uint32_t tile_cnt = 0;
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i) {
+            const uint32_t c = cnt[i][tid];
+            cnt[i][tid] = tile_cnt;
+            tile_cnt += c;
+        }
+        uint32_t before_tiles, digit_total;
+        if (self_prefix) {
+            before_tiles = 0;
+            digit_total = 0;
+            for (int t = 0; t < n_tiles; ++t) {
+                const uint32_t c = hist[(int64_t)tid * n_tiles + t];
+                if (t < tile) before_tiles += c;
+                digit_total += c;
+            }
+        } else {
+            before_tiles = hist[(int64_t)tid * n_tiles + tile];
+            digit_total = totals[tid];
+        }
+        uint32_t unused;
+        const uint32_t ls = block_exclusive_scan(tile_cnt, wave_sums, &unused);
+        const uint32_t digit_base = block_exclusive_scan(digit_total, wave_sums, &unused);
+        lstart[tid] = ls;
+        goff[tid] = digit_base + before_tiles - ls;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kIpt; ++r) {
+        if (wbase + r * 64 + lane < n) {
+            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t lp = lstart[d] + cnt[w][d] + rank[r];
+            skey[lp] = key[r];
+            sval[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const int64_t left = n - (int64_t)tile * kTile;
+    const int n_here = (int)(left < kTile ? left : kTile);
+    for (int j = tid; j < n_here; j += kThreads) {
+        const uint32_t k = skey[j];
+        const uint32_t pos = goff[(k >> shift) & mask] + (uint32_t)j;
+        out_keys[pos] = k;
+        out_vals[pos] = sval[j];
+    }
+}
+
+// Sorts the n entries (first.key(i), first.val(i)) by the low key_bits bits of the key, stably.  The result lands in
+// (keys_out, vals_out); (keys_tmp, vals_tmp) is the other half of the ping-pong (unused when one pass suffices).
+// counters: counter_bytes(n) bytes.
+template <class First, class Val>
+int sort_entries(const First& first, int64_t n, int key_bits, uint32_t* keys_out, Val* vals_out, uint32_t* keys_tmp,
+                 Val* vals_tmp, uint32_t* counters, hipStream_t s) {
+    if (n <= 0) return HMX_OK;
+    if (n >= ((int64_t)1 << 32)) return HMX_EINVAL;
+    const Passes pp = plan_passes(key_bits);
+    const int n_tiles = (int)n_tiles_for(n);
+    uint32_t* hist = counters;
+    uint32_t* totals = counters + (size_t)kDigits * n_tiles;
+    const int self_prefix = n_tiles <= kSelfPrefixTiles ? 1 : 0;
+    const uint32_t* src_keys = nullptr;
+    const Val* src_vals = nullptr;
+    for (int p = 0; p < pp.n; ++p) {
+        const bool to_out = ((pp.n - 1 - p) % 2) == 0;     // the last pass writes the output arrays
+        uint32_t* dk = to_out ? keys_out : keys_tmp;
+        Val* dv = to_out ? vals_out : vals_tmp;
+        const uint32_t mask = (1u << pp.bits[p]) - 1u;
+        if (p == 0) {
+            hipLaunchKernelGGL(radix_hist_kernel<First>, dim3(n_tiles), dim3(kThreads), 0, s, first, n, pp.shift[p], mask,
+                               n_tiles, hist);
+            if (!self_prefix) hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(kThreads), 0, s, hist, n_tiles, totals);
+            hipLaunchKernelGGL((radix_scatter_kernel<First, Val>), dim3(n_tiles), dim3(kThreads), 0, s, first, n, pp.shift[p],
+                               mask, n_tiles, hist, totals, self_prefix, dk, dv);
+        } else {
+            const FromArrays<Val> in{src_keys, src_vals};
+            hipLaunchKernelGGL(radix_hist_kernel<FromArrays<Val>>, dim3(n_tiles), dim3(kThreads), 0, s, in, n, pp.shift[p],
+                               mask, n_tiles, hist);
+            if (!self_prefix) hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(kThreads), 0, s, hist, n_tiles, totals);
+            hipLaunchKernelGGL((radix_scatter_kernel<FromArrays<Val>, Val>), dim3(n_tiles), dim3(kThreads), 0, s, in, n,
+                               pp.shift[p], mask, n_tiles, hist, totals, self_prefix, dk, dv);
+        }
+        src_keys = dk;
+        src_vals = dv;
+    }
+    return HMX_OK;
+}
+
+}  // namespace
+}  // namespace hmx_sort

@@ -8,9 +8,8 @@
 #include <cstring>
 #include <type_traits>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "hmx_common.h"
+#include "radix_sort.h"
 
 namespace hmx_seg {
 namespace {   // internal linkage: every translation unit that includes this header gets its own kernels
@@ -74,21 +73,23 @@ inline int lpr_log2_for(int64_t cpr) {
 }
 
 // ---------------------------------------------------------------- scatter-add ----------
-// Step 1: sort key = row id (or `sentinel` for entries that must not contribute), value = i.
+// Steps 1 and 2: sort key = row id (or `sentinel` for entries that must not contribute), value = Src::make_val(i);
+// the first pass of the sort reads them through this functor.
 template <class Src>
-__global__ __launch_bounds__(kBlock) void make_keys_kernel(Src src, const int64_t* __restrict__ ids,
-                                                           const int64_t* __restrict__ token_type, int64_t want_type,
-                                                           int64_t n, int64_t n_rows, int64_t padding_idx,
-                                                           uint32_t sentinel, uint32_t* __restrict__ keys,
-                                                           typename Src::Val* __restrict__ vals) {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+struct EntriesFromIds {
+    Src src;
+    const int64_t* ids;
+    const int64_t* token_type;
+    int64_t want_type, n_rows, padding_idx;
+    uint32_t sentinel;
+    __device__ __forceinline__ uint32_t key(int64_t i) const {
         const int64_t id = ids[i];
         bool ok = id >= 0 && id < n_rows && id != padding_idx;
         if (token_type != nullptr) ok = ok && token_type[i] == want_type;
-        keys[i] = ok ? (uint32_t)id : sentinel;
-        vals[i] = src.make_val(i);
+        return ok ? (uint32_t)id : sentinel;
     }
-}
+    __device__ __forceinline__ typename Src::Val val(int64_t i) const { return src.make_val(i); }
+};
 
 // Step 3 (pass 1): the sorted array is cut at every change of id AND at every multiple of kSuper entries into
 // "pieces"; a piece is summed sequentially in sorted (= original, the sort is stable) order, starting from zero.
@@ -348,17 +349,6 @@ inline int sort_bits(int64_t n_rows) {
     return b;
 }
 
-template <class Val>
-inline size_t rocprim_sort_temp_bytes(int64_t n, int bits) {
-    size_t bytes = 0;
-    uint32_t* p = nullptr;
-    Val* v = nullptr;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, p, p, v, v, (size_t)n, 0u, (unsigned)bits, hipStreamDefault);
-    if (e != hipSuccess) return 0;
-    return bytes;
-}
-
-
 constexpr int kMaxRowFloats = kStageBytes / 4;      // one row must fit an LDS stage
 constexpr int kMaxStagedLds = 2 * kStageBytes + 2 * kStageBytes;   // two stages + two carry rows at the widest row
 
@@ -371,8 +361,7 @@ inline size_t workspace_bytes(int64_t n, int64_t n_rows, int64_t d) {
     if (n <= 0 || n_rows <= 0 || d <= 0) return 256;
     const size_t karr = hmx_align_up((size_t)n * sizeof(uint32_t), 256);
     const size_t varr = hmx_align_up((size_t)n * sizeof(typename Src::Val), 256);
-    return 2 * karr + 2 * varr + 2 * piece_bytes(n, d, kSuper) +
-           hmx_align_up(rocprim_sort_temp_bytes<typename Src::Val>(n, sort_bits(n_rows)), 256) + 256;
+    return 2 * karr + 2 * varr + 2 * piece_bytes(n, d, kSuper) + hmx_sort::counter_bytes(n) + 256;
 }
 
 // table[ids[e]] += value(e) for e in [0, n).  `vec`: rows and table are 16-byte aligned and d % 4 == 0.
@@ -386,7 +375,6 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
     if (d > kMaxRowFloats) return HMX_EINVAL;
     const int bits = sort_bits(n_rows);
     using Val = typename Src::Val;
-    size_t temp_bytes = rocprim_sort_temp_bytes<Val>(n, bits);
     if (ws_bytes < workspace_bytes<Src>(n, n_rows, d) - 256) return HMX_EWORKSPACE;
     HmxCarver ws(workspace);
     uint32_t* keys = ws.take<uint32_t>(n);
@@ -395,18 +383,15 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
     Val* svals = ws.take<Val>(n);
     float* head_piece = ws.take<float>(piece_bytes(n, d, kSuper) / sizeof(float));
     float* tail_piece = ws.take<float>(piece_bytes(n, d, kSuper) / sizeof(float));
-    void* temp = ws.take<char>(temp_bytes);
+    uint32_t* counters = ws.take<uint32_t>(hmx_sort::counter_bytes(n) / sizeof(uint32_t));
     const uint32_t sentinel = (uint32_t)n_rows;
     if (sorted_keys_out) *sorted_keys_out = skeys;
     if (sentinel_out) *sentinel_out = sentinel;
 
-    const int grid1 = (int)std::min<int64_t>(hmx_ceil_div(n, kBlock), kMaxGrid);
-    hipLaunchKernelGGL(make_keys_kernel<Src>, dim3(grid1), dim3(kBlock), 0, s, src, ids, token_type, want_type, n,
-                       n_rows, padding_idx, sentinel, keys, vals);
+    const EntriesFromIds<Src> first{src, ids, token_type, want_type, n_rows, padding_idx, sentinel};
+    const int rc = hmx_sort::sort_entries(first, n, bits, skeys, svals, keys, vals, counters, s);
+    if (rc != HMX_OK) return rc;
     HMX_CHECK_LAUNCH();
-    if (rocprim::radix_sort_pairs(temp, temp_bytes, keys, skeys, vals, svals, (size_t)n, 0u, (unsigned)bits, s) !=
-        hipSuccess)
-        return HMX_ELAUNCH;
 
     const int64_t cpr = vec ? d / 4 : d;
     const int l2 = lpr_log2_for(cpr);

@@ -83,6 +83,25 @@ def test_scatter_add_extreme_skew_bit_exact(n, distinct, d):
     np.testing.assert_allclose(got[7], grad[ids == 7].double().sum(0).float().numpy(), rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("rows,n,d,dup", [(3_000_000, 600_000, 16, 0.5), (70_000, 300_000, 8, 0.0), (200, 270_000, 4, 0.0),
+                                          (4_000_001, 280_000, 64, 0.3), (65_536, 4097, 12, 0.0)])
+def test_scatter_add_multi_pass_sort_bit_exact(rows, n, d, dup):
+    """Enough entries for the sort's scanned tile prefixes (more than 64 tiles of 4096) and key widths of one, two
+    and three digits; `dup` of the entries repeat a few thousand ids, so equal keys sit in many tiles and any loss of
+    their original order would change the fp32 sums."""
+    g = torch.Generator().manual_seed(rows % 1000 + n)
+    ids = torch.randint(0, rows, (n,), generator=g)
+    n_dup = int(n * dup)
+    if n_dup:
+        pool = torch.randint(1, rows, (3000,), generator=g)
+        where = torch.randperm(n, generator=g)[:n_dup]
+        ids[where] = pool[torch.randint(0, 3000, (n_dup,), generator=g)]
+    grad = torch.randn(n, d, generator=g)
+    got = ops.scatter_add_rows(grad.to(DEV), ids.to(DEV), rows, padding_idx=0).cpu().numpy()
+    want = C.scatter_add_rows(grad.numpy(), ids.numpy(), rows, padding_idx=0)
+    assert np.array_equal(got, want)
+
+
 def test_scatter_add_is_deterministic_and_accumulates():
     g = torch.Generator().manual_seed(8)
     ids = torch.randint(0, 40, (30000,), generator=g).to(DEV)
