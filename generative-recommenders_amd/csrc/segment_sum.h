@@ -397,12 +397,7 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
     const int l2 = lpr_log2_for(cpr);
     const int64_t n_sb = hmx_ceil_div(n, kSuper);
     const int row_bytes = (int)d * 4;
-    static const int stage_cap = [] {
-        const char* e = getenv("HMX_SEG_STAGE_KB");
-        const int kb = e ? atoi(e) : 0;
-        return (kb >= 1 && kb * 1024 <= kStageBytes) ? kb * 1024 : kStageBytes;
-    }();
-    const int S = std::max(1, std::min(kBlock, std::max(stage_cap, row_bytes) / row_bytes));   // entries per LDS stage
+    const int S = std::max(1, std::min(kBlock, std::max(kStageBytes, row_bytes) / row_bytes));   // entries per LDS stage
     const int stage_bytes = (int)hmx_align_up((size_t)S * row_bytes, 1024);
     const int lds = 2 * stage_bytes + 2 * (int)hmx_align_up((size_t)row_bytes, 16);
     const int grid4 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid);

@@ -10,12 +10,11 @@ steps = float(sys.argv[2])
 topn = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 f = path if path.endswith(".csv") else glob.glob(os.path.join(path, "*", "*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
-groups = {"scan": ["scan_"], "linear": ["linear_kernel"], "wgrad": ["wgrad"], "fused block": ["ffn_", "pre_", "post_", "block_"],
-          "loss (nce + its run sums)": ["nce_", "segment_sum_balanced", "WeightedRows", "segment_join_kernel<4, 128>"],
+groups = {"hmx sort": ["radix_"], "scan": ["scan_"], "linear": ["linear_kernel"], "wgrad": ["wgrad"], "fused block": ["ffn_", "pre_", "post_", "block_"],
+          "loss (nce + its run sums)": ["nce_", "WeightedRows"],
           "optimizer + clip (torch)": ["multi_tensor", "fused_adam", "FusedAdam"], "rocprim sort": ["rocprim", "ROCPRIM"],
-          "hmx sort": ["radix_", "bucket_"],
           "top-k (miner)": ["coarse", "rescore", "seed_thr", "to_bf16", "warm"], "gather": ["gather_rows"], "conv": ["conv_silu"],
-          "scatter (plain rows)": ["PlainRows", "segment_join_kernel<4, 512>"],
+          "scatter (plain rows)": ["PlainRows"], "run joins (both)": ["segment_join_kernel"],
           "pointwise hmx": ["rmsnorm", "binary_", "combine_", "silu_rope", "colsum", "sum_groups", "seq_index", "attn1q"]}
 used = set()
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
