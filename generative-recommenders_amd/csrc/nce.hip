@@ -350,6 +350,53 @@ __global__ __launch_bounds__(256) void nce_project_table_rows_kernel(const uint3
     }
 }
 
+// Hard negatives with a repeating structure (hydra3.py:905-919 tiles each user's K mined ids over the n_hard slots of
+// every position of that user): inside a group of consecutive query rows [group_start[g], group_start[g + 1]) slot s
+// refers to the same table row as slot s % K of the group's first row.  The table gradient of the group is then a
+// small dense product: out[g * K + u] = sum_i (sum_{s = u, u + K, ...} coef[i, 1 + s]) * q_i, summed over the
+// group's rows in order -- K rows per group to scatter instead of n_hard per query.
+constexpr int kMaxPeriod = 64;
+__global__ __launch_bounds__(256) void nce_group_rows_kernel(const float* __restrict__ q, const float* __restrict__ coef,
+                                                             int64_t m, int C, int n_hard, int K,
+                                                             const int64_t* __restrict__ group_start,
+                                                             const int64_t* __restrict__ hard_ids, int cpr,
+                                                             float* __restrict__ out_rows, int64_t* __restrict__ out_ids) {
+    constexpr int UMAX = kMaxPeriod / 16;
+    const int lc = threadIdx.x & 15, lg = threadIdx.x >> 4;
+    const int64_t g = blockIdx.x;
+    int64_t r0 = group_start[g], r1 = group_start[g + 1];
+    r0 = r0 < 0 ? 0 : (r0 > m ? m : r0);
+    r1 = r1 < r0 ? r0 : (r1 > m ? m : r1);
+    if (threadIdx.x < K) out_ids[g * K + threadIdx.x] = (r1 > r0) ? hard_ids[r0 * n_hard + threadIdx.x] : -1;
+    for (int c = lc; c < cpr; c += 16) {
+        float4 acc[UMAX];
+#pragma unroll
+        for (int uu = 0; uu < UMAX; ++uu) acc[uu] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+        for (int64_t i = r0; i < r1; ++i) {
+            const float4 qv = reinterpret_cast<const float4*>(q)[i * cpr + c];
+            const float* ci = coef + i * C + 1;
+#pragma unroll
+            for (int uu = 0; uu < UMAX; ++uu) {
+                const int u = lg + 16 * uu;
+                if (u < K) {
+                    float cs = 0.f;
+                    for (int sl = u; sl < n_hard; sl += K) cs += ci[sl];
+                    acc[uu].x += cs * qv.x;
+                    acc[uu].y += cs * qv.y;
+                    acc[uu].z += cs * qv.z;
+                    acc[uu].w += cs * qv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int uu = 0; uu < UMAX; ++uu) {
+            const int u = lg + 16 * uu;
+            if (u < K) reinterpret_cast<float4*>(out_rows)[(g * K + u) * cpr + c] = acc[uu];
+        }
+    }
+}
+
 bool nce_shape_ok(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb) {
     if (m <= 0 || d <= 0 || d % 4 != 0 || d > 256 || n_hard < 0 || n_inb < 0) return false;
     if (n_hard > 0 && n_rows <= 0) return false;
@@ -414,6 +461,14 @@ extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_
     return HMX_OK;
 }
 
+namespace {
+size_t grouped_table_bytes(int64_t n_groups, int64_t period, int64_t n_rows, int64_t d) {
+    const int64_t n = n_groups * period;
+    return hmx_align_up((size_t)n * d * sizeof(float), 256) + hmx_align_up((size_t)n * sizeof(int64_t), 256) +
+           hmx_seg::workspace_bytes<PlainRows>(n, n_rows, d);
+}
+}  // namespace
+
 extern "C" size_t hmx_nce_bwd_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb) {
     if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb)) return 256;
     size_t a = n_inb > 0 ? hmx_seg::workspace_bytes<WeightedRows>(m * n_inb, m, d) : 256;
@@ -421,13 +476,23 @@ extern "C" size_t hmx_nce_bwd_workspace_bytes(int64_t m, int64_t d, int64_t n_ro
     return a > b ? a : b;
 }
 
-extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
-                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
-                               int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
-                               const float* q_inv, const float* k_inv, const float* grad_row_loss, float* dq,
-                               float* dk, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
-    HMX_ENTER();
+extern "C" size_t hmx_nce_bwd_grouped_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb,
+                                                      int64_t n_groups, int64_t period) {
+    if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb) || n_groups <= 0 || period <= 0) return 256;
+    size_t a = n_inb > 0 ? hmx_seg::workspace_bytes<WeightedRows>(m * n_inb, m, d) : 256;
+    size_t b = n_hard > 0 ? grouped_table_bytes(n_groups, period, n_rows, d) : 256;
+    return a > b ? a : b;
+}
+
+static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, const float* table,
+                        int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
+                        int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
+                        const float* q_inv, const float* k_inv, const float* grad_row_loss, float* dq,
+                        float* dk, float* dtable, const int64_t* group_start, int64_t n_groups, int64_t period,
+                        void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return HMX_OK;
+    const bool grouped = group_start != nullptr && n_hard > 0;
+    if (grouped && (n_groups <= 0 || period <= 0 || period > kMaxPeriod || period > n_hard)) return HMX_EINVAL;
     if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb) || !(temperature > 0.f)) return HMX_EINVAL;
     if (!q || !k || !logits || !lse || !q_inv || !k_inv || !grad_row_loss || !dq || !dk || !workspace)
         return HMX_EINVAL;
@@ -435,7 +500,9 @@ extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_
     if (!aligned16(q) || !aligned16(k) || !aligned16(dq) || !aligned16(dk) ||
         (n_hard > 0 && (!aligned16(table) || !aligned16(dtable))))
         return HMX_EINVAL;
-    if (workspace_bytes < hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb)) return HMX_EWORKSPACE;
+    if (workspace_bytes < (grouped ? hmx_nce_bwd_grouped_workspace_bytes(m, d, n_rows, n_hard, n_inb, n_groups, period)
+                                   : hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb)))
+        return HMX_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize,
                               logits, nullptr, const_cast<float*>(lse), const_cast<float*>(q_inv),
@@ -462,14 +529,29 @@ extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_
     // d table: hard-negative references, then the normalisation of each touched row (dtable holds only this
     // call's sums: it must be zero on entry)
     if (n_hard > 0) {
-        WeightedRows src{q, logits, (int)n_hard, C, 1};
         const uint32_t* skeys = nullptr;
         uint32_t sentinel = 0;
-        const int rc = sorted_segment_add(src, true, hard_ids, nullptr, 0, m * n_hard, d, dtable, n_rows, -1,
-                                          workspace, workspace_bytes, s, &skeys, &sentinel);
+        int64_t n = m * n_hard;
+        int rc;
+        if (grouped) {
+            n = n_groups * period;
+            HmxCarver ws(workspace);
+            float* rows = ws.take<float>((size_t)n * d);
+            int64_t* ids = ws.take<int64_t>(n);
+            const size_t used = hmx_align_up((size_t)n * d * sizeof(float), 256) + hmx_align_up((size_t)n * sizeof(int64_t), 256);
+            hipLaunchKernelGGL(nce_group_rows_kernel, dim3((unsigned)n_groups), dim3(256), 0, s, q, logits, m, C, (int)n_hard,
+                               (int)period, group_start, hard_ids, p.cpr, rows, ids);
+            HMX_CHECK_LAUNCH();
+            PlainRows src{rows};
+            rc = sorted_segment_add(src, true, ids, nullptr, 0, n, d, dtable, n_rows, -1,
+                                    static_cast<char*>(workspace) + used, workspace_bytes - used, s, &skeys, &sentinel);
+        } else {
+            WeightedRows src{q, logits, (int)n_hard, C, 1};
+            rc = sorted_segment_add(src, true, hard_ids, nullptr, 0, n, d, dtable, n_rows, -1, workspace, workspace_bytes,
+                                    s, &skeys, &sentinel);
+        }
         if (rc != HMX_OK) return rc;
         if (normalize) {
-            const int64_t n = m * n_hard;
             const unsigned grid = (unsigned)std::min<int64_t>(hmx_ceil_div(n, 16), 65536);
             hipLaunchKernelGGL(nce_project_table_rows_kernel, dim3(grid), dim3(256), 0, s, skeys, n, sentinel, table,
                                p.cpr, dtable);
@@ -478,4 +560,27 @@ extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_
     }
     hmx_profile_end(span, s);
     return HMX_OK;
+}
+
+extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
+                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
+                               int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
+                               const float* q_inv, const float* k_inv, const float* grad_row_loss, float* dq,
+                               float* dk, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
+    HMX_ENTER();
+    return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize, logits, lse,
+                        q_inv, k_inv, grad_row_loss, dq, dk, dtable, nullptr, 0, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
+                                       int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
+                                       int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
+                                       const float* q_inv, const float* k_inv, const float* grad_row_loss, float* dq,
+                                       float* dk, float* dtable, const int64_t* group_start, int64_t n_groups,
+                                       int64_t period, void* workspace, size_t workspace_bytes, void* stream) {
+    HMX_ENTER();
+    if (n_hard > 0 && !group_start) return HMX_EINVAL;
+    return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize, logits, lse,
+                        q_inv, k_inv, grad_row_loss, dq, dk, dtable, group_start, n_groups, period, workspace,
+                        workspace_bytes, stream);
 }

@@ -263,6 +263,15 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
                     V acc = continues[u] ? carry[((k - 1) & 1) * cpr + c] : vzero<VEC>();
                     const V* rowp = st + (s_pos[u] - e0) * cpr + c;
                     int e = s_pos[u];
+                    // long pieces: sixteen LDS row reads in flight, so the chain of additions, not the LDS latency,
+                    // sets the pace of a run that fills the stage
+                    for (; e + 16 <= e_pos[u]; e += 16, rowp += 16 * cpr) {
+                        V v[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = src.weigh(valL[e + i], rowp[i * cpr]);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) vadd(acc, v[i]);
+                    }
                     for (; e + 4 <= e_pos[u]; e += 4, rowp += 4 * cpr) {
                         const V v0 = rowp[0], v1 = rowp[cpr], v2 = rowp[2 * cpr], v3 = rowp[3 * cpr];
                         vadd(acc, src.weigh(valL[e], v0));

@@ -282,6 +282,7 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
     num_hard = int(T * hard_ratio)
     num_inb = T - num_hard
     hard_ids = None
+    hard_groups = None
     if hard_negatives is not None and num_hard > 0:                      # hydra3.py:905-919
         ch = hard_negatives[mask]
         K = ch.shape[1]
@@ -289,6 +290,12 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
             ch = torch.gather(ch, 1, torch.randint(0, K, (M, num_hard), device=device))
         else:
             ch = ch.repeat(1, (num_hard + K - 1) // K)[:, :num_hard]
+            # one list per user, broadcast over its positions (Hydra.forward): the rows of a user are consecutive in
+            # the masked order and share their ids, which the loss backward can use
+            if hard_negatives.dim() == 3 and hard_negatives.stride(1) == 0 and K <= 64 and q.is_cuda:
+                starts = torch.zeros(mask.shape[0] + 1, dtype=torch.int64, device=device)
+                starts[1:] = mask.sum(1).cumsum(0)
+                hard_groups = (starts, K)
         hard_ids = ch
     inb = None
     if num_inb > 0:                                                      # hydra3.py:921-950
@@ -303,9 +310,10 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
                 if item_table is not None:       # random table rows fill the batch's shortfall: more table keys
                     rid = torch.randint(1, item_table.shape[0], (M, short), device=device)
                     hard_ids = rid if hard_ids is None else torch.cat([hard_ids, rid], dim=1)
+                    hard_groups = None            # the extra random rows break the per-user repetition
                 else:
                     inb = torch.cat([inb, inb[:, -1:].expand(-1, short)], dim=1)
-    return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize).mean()
+    return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize, hard_groups=hard_groups).mean()
 
 
 class EnhancedTrainingLoss(nn.Module):

@@ -178,7 +178,7 @@ def gather_routed(item_weight, user_weight, ids, token_type):
 # --------------------------------------------------------------------------- fused InfoNCE
 class _FusedNCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, table, hard_ids, inb_idx, temperature, normalize):
+    def forward(ctx, q, k, table, hard_ids, inb_idx, temperature, normalize, hard_groups):
         _need_cuda(q, k, table, hard_ids, inb_idx)
         q, k = _f32c(q), _f32c(k)
         m, d = q.shape
@@ -199,6 +199,14 @@ class _FusedNCE(torch.autograd.Function):
         ctx.save_for_backward(q, k, tab, hid, iid, logits, lse, q_inv, k_inv)
         ctx.cfg = (float(temperature), int(bool(normalize)), n_rows, n_hard, n_inb)
         ctx.table_param = table
+        ctx.groups = None
+        if hard_groups is not None and n_hard > 0:
+            gs, period = hard_groups
+            gs = _i64c(gs)
+            _need_cuda(gs)
+            if not (1 <= int(period) <= min(64, n_hard)) or gs.numel() < 2:
+                raise hmx.HmxError("fused_nce_rows: hard_groups needs 1 <= period <= min(64, n_hard) and >= 1 group")
+            ctx.groups = (gs, int(period))
         return row_loss
 
     @staticmethod
@@ -221,21 +229,34 @@ class _FusedNCE(torch.autograd.Function):
         if dtable is None and n_hard > 0:
             dtable = torch.zeros(n_rows, d, dtype=torch.float32, device=dev)
         L = hmx.lib()
-        ws = workspace(L.hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb), dev)
         coef = logits   # overwritten with the key-gradient coefficients: backward may run once
-        hmx.check(L.hmx_nce_bwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
-                                    hmx.ptr(iid), n_inb, temperature, normalize, hmx.ptr(coef), hmx.ptr(lse),
-                                    hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq), hmx.ptr(dk),
-                                    hmx.ptr(dtable), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
-                  "hmx_nce_bwd_f32")
-        return dq, dk, (dtable if (want_table and fused_dst is None) else None), None, None, None, None
+        if ctx.groups is not None:
+            gs, period = ctx.groups
+            ng = gs.numel() - 1
+            ws = workspace(L.hmx_nce_bwd_grouped_workspace_bytes(m, d, n_rows, n_hard, n_inb, ng, period), dev)
+            hmx.check(L.hmx_nce_bwd_grouped_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
+                                                hmx.ptr(iid), n_inb, temperature, normalize, hmx.ptr(coef), hmx.ptr(lse),
+                                                hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq), hmx.ptr(dk),
+                                                hmx.ptr(dtable), hmx.ptr(gs), ng, period, hmx.ptr(ws), ws.numel(),
+                                                hmx.current_stream()), "hmx_nce_bwd_grouped_f32")
+        else:
+            ws = workspace(L.hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb), dev)
+            hmx.check(L.hmx_nce_bwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
+                                        hmx.ptr(iid), n_inb, temperature, normalize, hmx.ptr(coef), hmx.ptr(lse),
+                                        hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq), hmx.ptr(dk),
+                                        hmx.ptr(dtable), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
+                      "hmx_nce_bwd_f32")
+        return dq, dk, (dtable if (want_table and fused_dst is None) else None), None, None, None, None, None
 
 
-def fused_nce_rows(q, k, table, hard_ids, inb_idx, temperature=0.05, normalize=True):
+def fused_nce_rows(q, k, table, hard_ids, inb_idx, temperature=0.05, normalize=True, hard_groups=None):
     """Per-row InfoNCE loss over [positive k_i | table[hard_ids[i]] | k[inb_idx[i]]] (hydra3.py:845-974 with the
     sampling done by the caller).  q, k: (M, d); hard_ids: (M, n_hard) item-table rows or None; inb_idx:
-    (M, n_inb) rows of k or None.  Gradients flow to q, k and table.  backward() may run once."""
-    return _FusedNCE.apply(q, k, table, hard_ids, inb_idx, temperature, normalize)
+    (M, n_inb) rows of k or None.  Gradients flow to q, k and table.  backward() may run once.
+    hard_groups = (group_start (G + 1,) int64 offsets into the M rows, period): the caller's promise that inside each
+    group of consecutive rows hard_ids[i, s] == hard_ids[first row of the group, s % period] (the reference's tiling
+    of each user's mined ids); the table gradient is then built per group instead of per (row, slot) entry."""
+    return _FusedNCE.apply(q, k, table, hard_ids, inb_idx, temperature, normalize, hard_groups)
 
 
 # --------------------------------------------------------------------------- scoring + top-K

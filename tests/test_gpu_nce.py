@@ -35,7 +35,7 @@ def _case(M, d, R, n_hard, n_inb, seed, users=None, zero_rows=False):
     return q, k, table, hard, inb
 
 
-def _check(q, k, table, hard, inb, temperature=0.05, normalize=True):
+def _check(q, k, table, hard, inb, temperature=0.05, normalize=True, hard_groups=None):
     from oracle import hydra_oracle as O
     from generative_recommenders_amd import ops
     w = torch.randn(q.shape[0], generator=torch.Generator().manual_seed(1))     # non-uniform upstream gradient
@@ -45,7 +45,8 @@ def _check(q, k, table, hard, inb, temperature=0.05, normalize=True):
     dev = "cuda"
     gq, gk, gt = (t.to(dev).requires_grad_(True) for t in (q, k, table))
     got = ops.fused_nce_rows(gq, gk, gt, None if hard is None else hard.to(dev), None if inb is None else inb.to(dev),
-                             temperature, normalize)
+                             temperature, normalize,
+                             hard_groups=None if hard_groups is None else (hard_groups[0].to(dev), hard_groups[1]))
     (got * w.to(dev)).sum().backward()
     assert torch.allclose(got.detach().cpu(), want.detach(), atol=3e-5, rtol=1e-5), \
         float((got.detach().cpu() - want.detach()).abs().max())
@@ -72,6 +73,22 @@ def test_matches_oracle(M, d, R, n_hard, n_inb):
 
 def test_user_structured_hard_negatives():
     _check(*_case(900, 64, 20000, 153, 359, seed=3, users=12))
+
+
+@pytest.mark.parametrize("M,users,d,n_hard,period", [(900, 12, 64, 153, 50), (60, 40, 64, 153, 50), (500, 7, 128, 20, 7),
+                                                      (257, 30, 16, 64, 64), (100, 100, 32, 5, 1)])
+def test_grouped_hard_negative_backward(M, users, d, n_hard, period):
+    """The per-user form of the table gradient (hmx_nce_bwd_grouped_f32): rows of a user are consecutive and share
+    `period` ids tiled over the n_hard slots; some users have no rows at all.  Same oracle, same tolerances."""
+    g = torch.Generator().manual_seed(M + users)
+    q, k, table, _, inb = _case(M, d, 3000, 0, 40, seed=M)
+    per_user = torch.randint(1, 3000, (users, period), generator=g)
+    per_user[0, : min(3, period)] = per_user[1 % users, : min(3, period)]      # two users share some ids
+    owner = torch.sort(torch.randint(0, users, (M,), generator=g)).values
+    hard = per_user[owner].repeat(1, (n_hard + period - 1) // period)[:, :n_hard].contiguous()
+    starts = torch.zeros(users + 1, dtype=torch.int64)
+    starts[1:] = torch.bincount(owner, minlength=users).cumsum(0)
+    _check(q, k, table, hard, inb, hard_groups=(starts, period))
 
 
 def test_no_hard_or_no_inbatch():
