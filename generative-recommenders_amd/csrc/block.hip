@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "hmx_common.h"
+#include "profile.h"
 
 #pragma clang fp contract(fast)
 
@@ -870,7 +871,9 @@ extern "C" int hmx_block_pre_fwd(const hmx_block_args* a, void* stream) {
     if (!fill_common(p, a)) return HMX_EINVAL;
     if (p.T == 0) return HMX_OK;
     if (!p.x || !p.scale1 || !p.b1 || !p.cs || !p.sn || !p.rstd1 || !p.x_in || !p.z || !p.y2) return HMX_EINVAL;
+    void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     HMX_BLOCK_DISPATCH(block_pre_fwd_kernel, p, (size_t)0, (size_t)0, (hipStream_t)stream);
+    hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -882,7 +885,9 @@ extern "C" int hmx_block_post_fwd(const hmx_block_args* a, void* stream) {
     if (p.T == 0) return HMX_OK;
     if (!p.yg || !p.y2 || !p.x || !p.b2 || !p.scale2 || !p.out || !p.m || !p.rstd2 || (p.first && (!p.rstd1 || !p.scale1)))
         return HMX_EINVAL;
+    void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     HMX_BLOCK_DISPATCH(block_post_fwd_kernel, p, (size_t)0, (size_t)0, (hipStream_t)stream);
+    hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -895,7 +900,9 @@ extern "C" int hmx_block_post_bwd(const hmx_block_args* a, void* stream) {
     if (!p.dout || !p.m || !p.rstd2 || !p.scale2 || !p.yg || !p.y2 || !p.dyg || !p.dy2 || !p.dm || !p.hmid || !p.n2 || !p.dg ||
         !p.du || !p.p || !p.dy1 || !p.dscale_part)
         return HMX_EINVAL;
+    void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     HMX_BLOCK_DISPATCH(block_post_bwd_kernel, p, p.lay.wg, p.lay.w2t + pack_entries(p.lay.d, p.lay.d), (hipStream_t)stream);
+    hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -908,7 +915,9 @@ extern "C" int hmx_block_pre_bwd(const hmx_block_args* a, void* stream) {
     if (!p.x || !p.scale1 || !p.b1 || !p.cs || !p.sn || !p.dx_in || !p.dz || !p.dy2 || !p.dm || !p.dx || !p.s || !p.dx1 || !p.n ||
         !p.dscale_part)
         return HMX_EINVAL;
+    void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     HMX_BLOCK_DISPATCH(block_pre_bwd_kernel, p, p.lay.w1, p.lay.wint + p.lay.wint_stride * p.lay.H, (hipStream_t)stream);
+    hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }

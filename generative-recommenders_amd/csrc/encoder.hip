@@ -10,6 +10,7 @@
 #include <atomic>
 
 #include "hmx_common.h"
+#include "profile.h"
 
 // The library is built with -ffp-contract=off because the gather / scatter / scoring kernels promise bit-exact sums in
 // a stated order.  The encoder promises a tolerance instead (its projections run on bf16 MFMA), and its scan kernels
@@ -1214,8 +1215,10 @@ extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64
         gx = hmx_ceil_div(groups, hmx_ceil_div(groups, cap));
     }
     const dim3 grid((unsigned)gx, (unsigned)n_panels);
+    void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     if (g_linear_split) launch_linear<true>(ks, grid, lds, (hipStream_t)stream, p);
     else launch_linear<false>(ks, grid, lds, (hipStream_t)stream, p);
+    hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -1284,7 +1287,9 @@ extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n
     const int rc = wgrad_tickets_for_call(&p.tickets);
     if (rc != HMX_OK) return rc;
     const int64_t G = wgrad_groups(t_max, tiles);
+    void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)G, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
+    hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -1617,8 +1622,10 @@ extern "C" int hmx_scan_fwd(const float* xc, const float* xz, const float* dbc, 
     if (B == 0) return HMX_OK;
     if (!xc || !dbc || !Wdt || !bdt || !A_log || !D || !yg || L <= 0 || !scan_shape_ok(C, ED, H)) return HMX_EINVAL;
     ScanParams p{xc, xz, dbc, Wdt, bdt, A_log, D, (int)B, (int)L, (int)C, (int)ED, (int)H, yg, hs};
+    void* span = hmx_profile_begin("scan_fwd", (hipStream_t)stream);
     hipLaunchKernelGGL(scan_fwd_kernel, dim3((unsigned)B, (unsigned)hmx_ceil_div(C, 256)), dim3(256),
                        (size_t)kScanChunk * H * kP * 4, (hipStream_t)stream, p);
+    hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -1652,8 +1659,10 @@ extern "C" int hmx_scan_bwd(const float* xc, const float* xz, const float* dbc, 
     (void)attr64;
     (void)attr32;
     if (lds > 160 * 1024) return HMX_EINVAL;
+    void* span = hmx_profile_begin("scan_bwd", (hipStream_t)stream);
     if (ED >= 64) hipLaunchKernelGGL(scan_bwd_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, q);
     else hipLaunchKernelGGL(scan_bwd_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, q);
+    hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }

@@ -38,6 +38,8 @@ __device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
 // value(entry) = rows[entry]: the plain scatter-add of materialised gradient rows
 struct PlainRows {
     using Val = uint32_t;               // what travels with the key through the sort: the entry number
+    static constexpr int kPiece = 512;  // the sorted array is cut every kPiece entries (part of this op's contract)
+    static constexpr bool kBalanced = false;
     const float* rows;
     __device__ __forceinline__ Val make_val(int64_t e) const { return (uint32_t)e; }
     __device__ __forceinline__ int64_t row_index(Val v) const { return (int64_t)v; }
@@ -54,6 +56,8 @@ struct WeightedRows {
     // The coefficient rides through the sort next to the source row number, so the run loop reads it from the
     // sorted stream instead of chasing a random 4-byte load per entry.
     using Val = uint2;                  // (source row i, coefficient bits)
+    static constexpr int kPiece = 128;
+    static constexpr bool kBalanced = true;    // runs here are hundreds of entries long: one group per block of kPiece
     const float* rows;      // (n_src, d)
     const float* coef;      // (n_src, coef_stride)
     int per_row, coef_stride, col0;
@@ -125,8 +129,8 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // two stages, then two carry rows
     __shared__ uint32_t keyL[kSuper + 1];     // [nb] holds the key after the block
     __shared__ Val valL[kSuper];
-    __shared__ int piece_start[kSuper + 1];
-    __shared__ int sub_first[kSuper + 1];     // first piece of each sub-block
+    __shared__ uint16_t piece_start[kSuper + 2];   // 16-bit lists: two workgroups of the 8-byte-value form fit a CU
+    __shared__ uint16_t sub_first[kSuper + 2];     // first piece of each sub-block
     __shared__ int wave_cnt[2][kBlock / 64], wave_valid[2][kBlock / 64];
     __shared__ int carry_flag[2];             // "the carried piece began at a true run start"
     const int tid = threadIdx.x, lane = tid & 63;
@@ -177,14 +181,14 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
             }
         if (my_start[r]) {
             const int i = r * kBlock + tid;
-            piece_start[base + my_rank[r]] = i;
-            if (i % S == 0) sub_first[i / S] = base + my_rank[r];
+            piece_start[base + my_rank[r]] = (uint16_t)i;
+            if (i % S == 0) sub_first[i / S] = (uint16_t)(base + my_rank[r]);
         }
     }
     const int n_sub = (n_valid + S - 1) / S;
     if (tid == 0) {
-        piece_start[n_pieces] = n_valid;
-        sub_first[n_sub] = n_pieces;
+        piece_start[n_pieces] = (uint16_t)n_valid;
+        sub_first[n_sub] = (uint16_t)n_pieces;
     }
     __syncthreads();
 
@@ -303,6 +307,80 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
     }
 }
 
+// Pass 1, balanced form: one group walks one block of SB consecutive sorted entries, whatever runs it holds, so
+// every group has the same amount of work and long runs are summed by many groups at once.  Partial sums of runs
+// that cross a block boundary go to head_piece / tail_piece exactly as in segment_sum_staged_kernel (with kSuper = SB);
+// runs that lie inside one block are added to their row directly (one writer per row).
+template <int VEC, class Src, int SB>
+__global__ __launch_bounds__(kBlock) void segment_sum_balanced_kernel(Src src, const uint32_t* __restrict__ skeys,
+                                                                      const typename Src::Val* __restrict__ svals,
+                                                                      int64_t n, int cpr, int lpr_log2,
+                                                                      uint32_t sentinel, float* __restrict__ grad_table,
+                                                                      float* __restrict__ head_piece,
+                                                                      float* __restrict__ tail_piece) {
+    using V = typename VecT<VEC>::type;
+    constexpr int U = 8;   // entries requested per trip (summed in order)
+    static_assert(SB % U == 0, "block size must be a multiple of the prefetch depth");
+    const int lpr = 1 << lpr_log2;
+    const int lane_c = threadIdx.x & (lpr - 1);
+    const int groups_per_block = kBlock >> lpr_log2;
+    const int64_t n_sb = (n + SB - 1) / SB;
+    for (int64_t b = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> lpr_log2); b < n_sb;
+         b += (int64_t)gridDim.x * groups_per_block) {
+        const int64_t j0 = b * SB;
+        const int64_t j1 = (j0 + SB < n) ? j0 + SB : n;
+        const uint32_t key_before = (j0 > 0) ? skeys[j0 - 1] : sentinel;
+        const uint32_t key_after = (j1 < n) ? skeys[j1] : sentinel;
+        for (int c = lane_c; c < cpr; c += lpr) {
+            V acc = vzero<VEC>();
+            uint32_t cur = skeys[j0];
+            bool first_run = true;   // the run being summed began at j0 (it may continue an older block's run)
+            auto flush = [&](bool ends_here) {
+                if (cur == sentinel) return;
+                const bool starts_true = !(first_run && cur == key_before);
+                V* dst;
+                if (starts_true && ends_here) {
+                    dst = reinterpret_cast<V*>(grad_table) + (int64_t)cur * cpr + c;
+                    V t = *dst;
+                    vadd(t, acc);
+                    *dst = t;
+                } else if (!starts_true) {
+                    reinterpret_cast<V*>(head_piece)[b * cpr + c] = acc;
+                } else {
+                    reinterpret_cast<V*>(tail_piece)[b * cpr + c] = acc;
+                }
+            };
+            for (int64_t e = j0; e < j1; e += U) {
+                uint32_t key[U];
+                typename Src::Val sv[U];
+                V v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) key[u] = (e + u < j1) ? skeys[e + u] : sentinel;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (key[u] != sentinel) sv[u] = svals[e + u];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    v[u] = (key[u] != sentinel)
+                               ? src.weigh(sv[u], reinterpret_cast<const V*>(src.rows)[src.row_index(sv[u]) * cpr + c])
+                               : vzero<VEC>();
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (e + u >= j1) break;
+                    if (key[u] != cur) {
+                        flush(true);
+                        acc = vzero<VEC>();
+                        cur = key[u];
+                        first_run = false;
+                    }
+                    if (key[u] != sentinel) vadd(acc, v[u]);
+                }
+            }
+            flush(cur != key_after);
+        }
+    }
+}
+
 // Pass 2: one group per block b of SB entries; acts only if a run starts inside b and continues past its end.
 template <int VEC, int SB>
 __global__ __launch_bounds__(kBlock) void segment_join_kernel(const uint32_t* __restrict__ skeys, int64_t n, int cpr,
@@ -370,7 +448,7 @@ inline size_t workspace_bytes(int64_t n, int64_t n_rows, int64_t d) {
     if (n <= 0 || n_rows <= 0 || d <= 0) return 256;
     const size_t karr = hmx_align_up((size_t)n * sizeof(uint32_t), 256);
     const size_t varr = hmx_align_up((size_t)n * sizeof(typename Src::Val), 256);
-    return 2 * karr + 2 * varr + 2 * piece_bytes(n, d, kSuper) + hmx_sort::counter_bytes(n) + 256;
+    return 2 * karr + 2 * varr + 2 * piece_bytes(n, d, Src::kPiece) + hmx_sort::counter_bytes(n) + 256;
 }
 
 // table[ids[e]] += value(e) for e in [0, n).  `vec`: rows and table are 16-byte aligned and d % 4 == 0.
@@ -390,8 +468,8 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
     Val* vals = ws.take<Val>(n);
     uint32_t* skeys = ws.take<uint32_t>(n);
     Val* svals = ws.take<Val>(n);
-    float* head_piece = ws.take<float>(piece_bytes(n, d, kSuper) / sizeof(float));
-    float* tail_piece = ws.take<float>(piece_bytes(n, d, kSuper) / sizeof(float));
+    float* head_piece = ws.take<float>(piece_bytes(n, d, Src::kPiece) / sizeof(float));
+    float* tail_piece = ws.take<float>(piece_bytes(n, d, Src::kPiece) / sizeof(float));
     uint32_t* counters = ws.take<uint32_t>(hmx_sort::counter_bytes(n) / sizeof(uint32_t));
     const uint32_t sentinel = (uint32_t)n_rows;
     if (sorted_keys_out) *sorted_keys_out = skeys;
@@ -404,29 +482,33 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
 
     const int64_t cpr = vec ? d / 4 : d;
     const int l2 = lpr_log2_for(cpr);
-    const int64_t n_sb = hmx_ceil_div(n, kSuper);
+    static_assert(Src::kBalanced || Src::kPiece == kSuper, "the staged kernel cuts at kSuper");
+    constexpr int SB = Src::kPiece;
+    const int64_t n_sb = hmx_ceil_div(n, SB);
     const int row_bytes = (int)d * 4;
     const int S = std::max(1, std::min(kBlock, std::max(kStageBytes, row_bytes) / row_bytes));   // entries per LDS stage
     const int stage_bytes = (int)hmx_align_up((size_t)S * row_bytes, 1024);
     const int lds = 2 * stage_bytes + 2 * (int)hmx_align_up((size_t)row_bytes, 16);
+    const int grid3 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid * 4);
     const int grid4 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid);
-    if (vec) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&segment_sum_staged_kernel<4, Src>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedLds);
-        (void)attr;
-        hipLaunchKernelGGL((segment_sum_staged_kernel<4, Src>), dim3((unsigned)n_sb), dim3(kBlock), lds, s, src, skeys, svals,
-                           n, (int)cpr, l2, S, stage_bytes, sentinel, table, head_piece, tail_piece);
-        hipLaunchKernelGGL((segment_join_kernel<4, kSuper>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
-                           sentinel, table, head_piece, tail_piece);
-    } else {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&segment_sum_staged_kernel<1, Src>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxStagedLds);
-        (void)attr;
-        hipLaunchKernelGGL((segment_sum_staged_kernel<1, Src>), dim3((unsigned)n_sb), dim3(kBlock), lds, s, src, skeys, svals,
-                           n, (int)cpr, l2, S, stage_bytes, sentinel, table, head_piece, tail_piece);
-        hipLaunchKernelGGL((segment_join_kernel<1, kSuper>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2,
-                           sentinel, table, head_piece, tail_piece);
-    }
+    auto run = [&](auto vec_tag) {
+        constexpr int VEC = decltype(vec_tag)::value;
+        if constexpr (Src::kBalanced) {
+            hipLaunchKernelGGL((segment_sum_balanced_kernel<VEC, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
+                               n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+        } else {
+            static const hipError_t attr = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&segment_sum_staged_kernel<VEC, Src>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                kMaxStagedLds);
+            (void)attr;
+            hipLaunchKernelGGL((segment_sum_staged_kernel<VEC, Src>), dim3((unsigned)n_sb), dim3(kBlock), lds, s, src, skeys,
+                               svals, n, (int)cpr, l2, S, stage_bytes, sentinel, table, head_piece, tail_piece);
+        }
+        hipLaunchKernelGGL((segment_join_kernel<VEC, SB>), dim3(grid4), dim3(kBlock), 0, s, skeys, n, (int)cpr, l2, sentinel,
+                           table, head_piece, tail_piece);
+    };
+    if (vec) run(std::integral_constant<int, 4>{});
+    else run(std::integral_constant<int, 1>{});
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
