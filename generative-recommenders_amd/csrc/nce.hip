@@ -42,6 +42,21 @@ struct NceParams {
     float* k_inv;             // (m)
     const float* grad_row_loss;   // (m)   backward only
     float* dq;                    // (m, d) backward only
+    int period;                   // > 0: hard_ids[i, s] == hard_ids[i, s % period]; only the first `period` hard slots
+                                  // are evaluated, each weighted by the number of slots it stands for
+};
+
+// The slots a kernel walks: all C of them, or with periodic hard negatives the positive, the first `period` hard
+// slots and the in-batch slots.  real() maps a walked slot to its column of the logits matrix, copies() is how many
+// columns it stands for.
+struct SlotWalk {
+    int n_hard, kh, n_walk;
+    __device__ __forceinline__ explicit SlotWalk(const NceParams& p)
+        : n_hard(p.n_hard), kh(p.period > 0 ? p.period : p.n_hard), n_walk(1 + kh + p.n_inb) {}
+    __device__ __forceinline__ int real(int v) const { return v <= kh ? v : v - kh + n_hard; }
+    __device__ __forceinline__ float copies(int v) const {
+        return (v >= 1 && v <= kh && kh != n_hard) ? (float)((n_hard - v + kh) / kh) : 1.0f;
+    }
 };
 
 template <int CTRL>
@@ -112,6 +127,7 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= p.m) return;   // wave-uniform
     const int C = 1 + p.n_hard + p.n_inb;
+    const SlotWalk walk(p);
     float4 qv[NCH];
     const float qs = p.q_inv[i] * p.inv_temp;
 #pragma unroll
@@ -122,11 +138,14 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
         qv[ch] = make_float4(v.x * qs, v.y * qs, v.z * qs, v.w * qs);
     }
     float mx = -INFINITY, sm = 0.f, l0 = 0.f;
-    for (int c0 = 0; c0 < C; c0 += 4 * kStepsInFlight) {
+    for (int c0 = 0; c0 < walk.n_walk; c0 += 4 * kStepsInFlight) {
         KeyRef ref[kStepsInFlight];
         float4 v[kStepsInFlight][NCH];
 #pragma unroll
-        for (int u = 0; u < kStepsInFlight; ++u) ref[u] = locate_key(p, i, c0 + 4 * u + grp, C);
+        for (int u = 0; u < kStepsInFlight; ++u) {
+            const int vs = c0 + 4 * u + grp;
+            ref[u] = locate_key(p, i, vs < walk.n_walk ? walk.real(vs) : C, C);
+        }
 #pragma unroll
         for (int u = 0; u < kStepsInFlight; ++u)
 #pragma unroll
@@ -136,7 +155,8 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
             }
 #pragma unroll
         for (int u = 0; u < kStepsInFlight; ++u) {
-            const int slot = c0 + 4 * u + grp;
+            const int vs = c0 + 4 * u + grp;
+            const int slot = vs < walk.n_walk ? walk.real(vs) : C;
             float dot = 0.f, ss = 0.f;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
             if (slot < C) {
                 if (lc == 0) p.logits[i * C + slot] = logit;
                 const float nm = fmaxf(mx, logit);
-                sm = sm * expf(mx - nm) + expf(logit - nm);   // exp(-inf) = 0 on the first key
+                sm = sm * expf(mx - nm) + walk.copies(vs) * expf(logit - nm);   // exp(-inf) = 0 on the first key
                 mx = nm;
                 if (slot == 0) l0 = logit;
             }
@@ -182,6 +202,7 @@ __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= p.m) return;
     const int C = 1 + p.n_hard + p.n_inb;
+    const SlotWalk walk(p);
     const float qinv = p.q_inv[i], lse = p.lse[i], g = p.grad_row_loss[i] * p.inv_temp;
     float4 qn[NCH], acc[NCH];
 #pragma unroll
@@ -192,13 +213,14 @@ __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
         qn[ch] = make_float4(v.x * qinv, v.y * qinv, v.z * qinv, v.w * qinv);
         acc[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int c0 = 0; c0 < C; c0 += 4 * kStepsInFlight) {
+    for (int c0 = 0; c0 < walk.n_walk; c0 += 4 * kStepsInFlight) {
         KeyRef ref[kStepsInFlight];
         float4 v[kStepsInFlight][NCH];
         float lg[kStepsInFlight];
 #pragma unroll
         for (int u = 0; u < kStepsInFlight; ++u) {
-            const int slot = c0 + 4 * u + grp;
+            const int vs = c0 + 4 * u + grp;
+            const int slot = vs < walk.n_walk ? walk.real(vs) : C;
             ref[u] = locate_key(p, i, slot, C);
             lg[u] = slot < C ? p.logits[i * C + slot] : 0.f;
         }
@@ -211,7 +233,8 @@ __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
             }
 #pragma unroll
         for (int u = 0; u < kStepsInFlight; ++u) {
-            const int slot = c0 + 4 * u + grp;
+            const int vs = c0 + 4 * u + grp;
+            const int slot = vs < walk.n_walk ? walk.real(vs) : C;
             float inv = ref[u].inv;
             if (ref[u].kind == 2) {
                 float ss = 0.f;
@@ -221,7 +244,8 @@ __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
                 inv = p.normalize ? 1.0f / fmaxf(sqrtf(ss), kNormEps) : 1.0f;
             }
             if (slot < C) {
-                const float w = (expf(lg[u] - lse) - (slot == 0 ? 1.f : 0.f)) * g;   // dL / d <qn, keyn>
+                // dL / d <qn, keyn>, for all the slots this one stands for
+                const float w = (expf(lg[u] - lse) - (slot == 0 ? 1.f : 0.f)) * g * walk.copies(vs);
                 const float wk = w * inv;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(256) void nce_project_table_rows_kernel(const uint3
 // group's rows in order -- K rows per group to scatter instead of n_hard per query.
 constexpr int kMaxPeriod = 64;
 __global__ __launch_bounds__(256) void nce_group_rows_kernel(const float* __restrict__ q, const float* __restrict__ coef,
-                                                             int64_t m, int C, int n_hard, int K,
+                                                             int64_t m, int C, int n_hard, int K, int summed,
                                                              const int64_t* __restrict__ group_start,
                                                              const int64_t* __restrict__ hard_ids, int cpr,
                                                              float* __restrict__ out_rows, int64_t* __restrict__ out_ids) {
@@ -381,7 +405,8 @@ __global__ __launch_bounds__(256) void nce_group_rows_kernel(const float* __rest
                 const int u = lg + 16 * uu;
                 if (u < K) {
                     float cs = 0.f;
-                    for (int sl = u; sl < n_hard; sl += K) cs += ci[sl];
+                    if (summed) cs = ci[u];               // the coefficient already stands for all repeats of the slot
+                    else for (int sl = u; sl < n_hard; sl += K) cs += ci[sl];
                     acc[uu].x += cs * qv.x;
                     acc[uu].y += cs * qv.y;
                     acc[uu].z += cs * qv.z;
@@ -436,12 +461,12 @@ bool aligned16(const void* a) { return (reinterpret_cast<uintptr_t>(a) & 15) == 
 
 }  // namespace
 
-extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
-                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
-                               int64_t n_inb, float temperature, int normalize, float* logits, float* row_loss,
-                               float* lse, float* q_inv, float* k_inv, void* stream) {
-    HMX_ENTER();
+static int nce_fwd_impl(const float* q, const float* k, int64_t m, int64_t d, const float* table,
+                        int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
+                        int64_t n_inb, int64_t period, float temperature, int normalize, float* logits, float* row_loss,
+                        float* lse, float* q_inv, float* k_inv, void* stream) {
     if (m == 0) return HMX_OK;
+    if (period < 0 || period > n_hard) return HMX_EINVAL;
     if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb) || !(temperature > 0.f)) return HMX_EINVAL;
     if (!q || !k || !logits || !row_loss || !lse || !q_inv || !k_inv) return HMX_EINVAL;
     if ((n_hard > 0 && (!table || !hard_ids)) || (n_inb > 0 && !inb_idx)) return HMX_EINVAL;
@@ -449,6 +474,7 @@ extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_
     hipStream_t s = (hipStream_t)stream;
     NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize,
                               logits, row_loss, lse, q_inv, k_inv);
+    p.period = (int)period;
     const unsigned g16 = (unsigned)hmx_ceil_div(m, 16), g4 = (unsigned)hmx_ceil_div(m, 4);
     hipLaunchKernelGGL(inv_norm_kernel, dim3(g16), dim3(256), 0, s, q, m, p.cpr, normalize, q_inv);
     hipLaunchKernelGGL(inv_norm_kernel, dim3(g16), dim3(256), 0, s, k, m, p.cpr, normalize, k_inv);
@@ -459,6 +485,26 @@ extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_
     hmx_profile_end(span, s);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
+}
+
+extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
+                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
+                               int64_t n_inb, float temperature, int normalize, float* logits, float* row_loss,
+                               float* lse, float* q_inv, float* k_inv, void* stream) {
+    HMX_ENTER();
+    return nce_fwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, 0, temperature, normalize, logits,
+                        row_loss, lse, q_inv, k_inv, stream);
+}
+
+extern "C" int hmx_nce_fwd_periodic_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
+                                        int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, int64_t period,
+                                        const int64_t* inb_idx, int64_t n_inb, float temperature, int normalize,
+                                        float* logits, float* row_loss, float* lse, float* q_inv, float* k_inv,
+                                        void* stream) {
+    HMX_ENTER();
+    if (period <= 0) return HMX_EINVAL;
+    return nce_fwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, period, temperature, normalize, logits,
+                        row_loss, lse, q_inv, k_inv, stream);
 }
 
 namespace {
@@ -509,6 +555,7 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
                               const_cast<float*>(k_inv));
     p.grad_row_loss = grad_row_loss;
     p.dq = dq;
+    p.period = grouped ? (int)period : 0;
     const int C = (int)(1 + n_hard + n_inb);
     const unsigned g16 = (unsigned)hmx_ceil_div(m, 16), g4 = (unsigned)hmx_ceil_div(m, 4);
     void* span = hmx_profile_begin("nce_bwd", s);
@@ -540,7 +587,7 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
             int64_t* ids = ws.take<int64_t>(n);
             const size_t used = hmx_align_up((size_t)n * d * sizeof(float), 256) + hmx_align_up((size_t)n * sizeof(int64_t), 256);
             hipLaunchKernelGGL(nce_group_rows_kernel, dim3((unsigned)n_groups), dim3(256), 0, s, q, logits, m, C, (int)n_hard,
-                               (int)period, group_start, hard_ids, p.cpr, rows, ids);
+                               (int)period, 1, group_start, hard_ids, p.cpr, rows, ids);
             HMX_CHECK_LAUNCH();
             PlainRows src{rows};
             rc = sorted_segment_add(src, true, ids, nullptr, 0, n, d, dtable, n_rows, -1,

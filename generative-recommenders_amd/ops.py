@@ -192,21 +192,29 @@ class _FusedNCE(torch.autograd.Function):
         logits = torch.empty(m, 1 + n_hard + n_inb, dtype=torch.float32, device=dev)
         row_loss, lse, q_inv, k_inv = (torch.empty(m, dtype=torch.float32, device=dev) for _ in range(4))
         n_rows = 0 if tab is None else tab.shape[0]
-        hmx.check(hmx.lib().hmx_nce_fwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
-                                            hmx.ptr(iid), n_inb, float(temperature), int(bool(normalize)),
-                                            hmx.ptr(logits), hmx.ptr(row_loss), hmx.ptr(lse), hmx.ptr(q_inv),
-                                            hmx.ptr(k_inv), hmx.current_stream()), "hmx_nce_fwd_f32")
-        ctx.save_for_backward(q, k, tab, hid, iid, logits, lse, q_inv, k_inv)
-        ctx.cfg = (float(temperature), int(bool(normalize)), n_rows, n_hard, n_inb)
-        ctx.table_param = table
-        ctx.groups = None
+        groups = None
         if hard_groups is not None and n_hard > 0:
             gs, period = hard_groups
             gs = _i64c(gs)
             _need_cuda(gs)
             if not (1 <= int(period) <= min(64, n_hard)) or gs.numel() < 2:
                 raise hmx.HmxError("fused_nce_rows: hard_groups needs 1 <= period <= min(64, n_hard) and >= 1 group")
-            ctx.groups = (gs, int(period))
+            groups = (gs, int(period))
+        if groups is not None:
+            hmx.check(hmx.lib().hmx_nce_fwd_periodic_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid),
+                                                         n_hard, groups[1], hmx.ptr(iid), n_inb, float(temperature),
+                                                         int(bool(normalize)), hmx.ptr(logits), hmx.ptr(row_loss),
+                                                         hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv),
+                                                         hmx.current_stream()), "hmx_nce_fwd_periodic_f32")
+        else:
+            hmx.check(hmx.lib().hmx_nce_fwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
+                                                hmx.ptr(iid), n_inb, float(temperature), int(bool(normalize)),
+                                                hmx.ptr(logits), hmx.ptr(row_loss), hmx.ptr(lse), hmx.ptr(q_inv),
+                                                hmx.ptr(k_inv), hmx.current_stream()), "hmx_nce_fwd_f32")
+        ctx.save_for_backward(q, k, tab, hid, iid, logits, lse, q_inv, k_inv)
+        ctx.cfg = (float(temperature), int(bool(normalize)), n_rows, n_hard, n_inb)
+        ctx.table_param = table
+        ctx.groups = groups
         return row_loss
 
     @staticmethod

@@ -171,13 +171,21 @@ int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const 
                     float temperature, int normalize, float* logits, const float* lse, const float* q_inv,
                     const float* k_inv, const float* grad_row_loss, float* dq, float* dk, float* dtable,
                     void* workspace, size_t workspace_bytes, void* stream);
-/* The same backward for hard negatives that repeat inside groups of consecutive query rows, which is how
- * hydra3.py:905-919 builds them (each user's K mined ids, tiled over the n_hard slots of all of that user's
- * positions): for every row i of group g = [group_start[g], group_start[g + 1]) (n_groups + 1 ascending offsets into
- * the m rows, on the device), hard_ids[i, s] == hard_ids[group_start[g], s % period].  The caller guarantees that;
- * the table gradient is then formed per group as a (period x rows-of-the-group) x (rows x d) product and only
- * n_groups * period rows are scattered instead of m * n_hard.  dq and dk are the same as hmx_nce_bwd_f32's; the
- * table rows differ from it by fp32 summation order only.  period <= 64, period <= n_hard. */
+/* Hard negatives that repeat, which is how hydra3.py:905-919 builds them (each user's K mined ids, tiled over the n_hard
+ * slots of all of that user's positions).
+ * hmx_nce_fwd_periodic_f32: the caller guarantees hard_ids[i, s] == hard_ids[i, s % period] for every row; only the
+ * first `period` hard slots are scored and each enters the log-sum-exp as many times as it is repeated.  Same row_loss
+ * as hmx_nce_fwd_f32 up to fp32 summation order; of the hard columns of `logits` only the first `period` are written.
+ * hmx_nce_bwd_grouped_f32: the backward for logits that came from hmx_nce_fwd_periodic_f32 with the same period, when
+ * in addition the rows form groups [group_start[g], group_start[g + 1]) (n_groups + 1 ascending offsets into the m
+ * rows, on the device) whose rows all carry the list of the group's first row.  The table gradient is then formed
+ * per group as a (period x rows-of-the-group) x (rows x d) product and only n_groups * period rows are scattered
+ * instead of m * n_hard.  dq, dk and the table rows equal hmx_nce_bwd_f32's up to fp32 summation order.
+ * period <= 64, period <= n_hard. */
+int hmx_nce_fwd_periodic_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
+                             const int64_t* hard_ids, int64_t n_hard, int64_t period, const int64_t* inb_idx,
+                             int64_t n_inb, float temperature, int normalize, float* logits, float* row_loss, float* lse,
+                             float* q_inv, float* k_inv, void* stream);
 size_t hmx_nce_bwd_grouped_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb,
                                            int64_t n_groups, int64_t period);
 int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
