@@ -233,7 +233,7 @@ def main():
             from bench_train import run_train
             t = run_train(args, world, rank)
             out["train_step"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "fwd_bwd_ms", "config",
-                                                   "roofline", "other_kernels", "cpu_baseline", "loss") if k in t}
+                                                   "roofline", "encoder", "other_kernels", "cpu_baseline", "loss") if k in t}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -28,31 +28,40 @@ def _sync(world):
 
 def cpu_baseline_train(args, seconds_cap=40.0):
     """The CPU oracle (fixture-verified restatement of the reference) on this box's host cores: one forward +
-    backward of the same model (1 M users, 4 M items, d 64, L 100) on a bounded batch of 32 sequences."""
+    backward of the same model (1 M users, 4 M items, d 64, L 100) on a bounded batch sized to about 15 s of CPU work."""
     from oracle import hydra_oracle as O
     from generative_recommenders_amd import synth
     threads = torch.get_num_threads()
-    B = 32
     model = O.build_model(args.users, args.items, d=args.dim, L=args.seq_len, dropout=0.2, seed=1).train()
-    bt = synth.train_batch(B, args.seq_len, args.users, args.items, "cpu", seed=2)
-    feat = [[] for _ in range(B)]
-    t0 = time.time()
-    loss = model(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"],
-                 bt["act"], bt["dwell"])
-    loss.backward()
-    dt = time.time() - t0
+
+    def one(B, seed):
+        bt = synth.train_batch(B, args.seq_len, args.users, args.items, "cpu", seed=seed)
+        feat = [[] for _ in range(B)]
+        t0 = time.time()
+        loss = model(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"],
+                     bt["act"], bt["dwell"])
+        loss.backward()
+        return time.time() - t0
+
+    # a 4-sequence pass sizes the sample so that it is about 15 s of CPU work (at most 256 sequences)
+    t4 = one(4, 2)
+    B = int(max(4, min(256, 15.0 / max(t4 / 4, 1e-3))))
+    model.zero_grad(set_to_none=True)
+    dt = one(B, 3)
     # BASELINE.json configs[0]: encoder forward only (log2feats, eval mode), batch 128, on the same host cores
     model.eval()
-    be = synth.train_batch(128, args.seq_len, args.users, args.items, "cpu", seed=3)
+    Be = max(4, min(128, B))
+    be = synth.train_batch(Be, args.seq_len, args.users, args.items, "cpu", seed=3)
     t1 = time.time()
     with torch.no_grad():
-        model.log2feats(be["seq"], [[] for _ in range(128)], be["tok"], be["ts"], be["act"], be["dwell"])
+        model.log2feats(be["seq"], [[] for _ in range(Be)], be["tok"], be["ts"], be["act"], be["dwell"])
     de = time.time() - t1
     return {"value": B / dt, "unit": "user seqs/s", "cores": threads, "kind": "port",
             "sample": f"one fwd+bwd of {B} sequences x {args.seq_len}, same model and tables, PyTorch CPU oracle on "
                       f"{threads} threads ({dt:.1f} s)",
-            "encoder_fwd_batch128": {"value": 128 / de, "unit": "user seqs/s",
-                                     "sample": f"log2feats forward of 128 sequences x {args.seq_len}, eval mode ({de:.1f} s)"}}
+            "encoder_fwd": {"value": Be / de, "unit": "user seqs/s",
+                            "sample": f"log2feats forward of {Be} sequences x {args.seq_len}, eval mode ({de:.1f} s)"
+                                      + (" = BASELINE.json configs[0]" if (Be, args.seq_len, args.dim) == (128, 100, 64) else "")}}
 
 
 def run_train(args, world, rank, with_cpu_baseline=True):
@@ -70,6 +79,7 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     # single-kernel implementation of the same update (one pass over the 1.28 GB of tables instead of nine)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1,
                             fused=not getattr(args, "foreach_adamw", False))
+    params = list(model.parameters())
     bt = synth.train_batch(B, L, args.users, args.items, dev, seed=99 + rank)
     feat = [[] for _ in range(B)]
     sync_grads = None
@@ -87,14 +97,15 @@ def run_train(args, world, rank, with_cpu_baseline=True):
             timers[-1].record()
         if sync_grads is not None:
             sync_grads()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
         opt.step()
         return loss
 
     for _ in range(max(args.warmup, 1)):
         step()
     hmx.profile_enable(True)
-    for tag in ("gather_rows", "scatter_segment_sum", "topk_coarse_bf16"):
+    TAGS = ("gather_rows", "scatter_segment_sum", "topk_coarse_bf16", "proj", "scan_fwd", "scan_bwd", "nce_fwd", "nce_bwd")
+    for tag in TAGS:
         hmx.profile_collect(tag)
     _sync(world)
     starts, mids = [], []
@@ -109,7 +120,7 @@ def run_train(args, world, rank, with_cpu_baseline=True):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    spans = {tag: hmx.profile_collect(tag) for tag in ("gather_rows", "scatter_segment_sum", "topk_coarse_bf16")}
+    spans = {tag: hmx.profile_collect(tag) for tag in TAGS}
     hmx.profile_enable(False)
     fwd_bwd_ms = sum(s.elapsed_time(m) for s, m in zip(starts, mids)) / args.steps
     step_s = elapsed / args.steps
@@ -122,27 +133,67 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     miner_tf = 2.0 * B * (args.items + 1) * d * args.steps / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
     s_ms, s_n = spans["scatter_segment_sum"]
 
+    # Encoder projections (everything that runs on the matrix cores: the fused block halves, the stand-alone
+    # projections and the weight gradients).  FLOPs per token and block, forward: 5 d x d products + per head in_proj
+    # (hd -> 2 ED), deltaBC (ED -> R + 2 N), out_proj (ED -> hd); the dt projection (R -> ED) runs inside the scan
+    # kernel and is left out of both sides.  Backward = 2 x forward.  Blocks: first + 2 + long-term at L, mid-term
+    # at min(25, L), short-term at min(10, L) (hydra3.py:460-548, 618-681).
+    H, R, N = 2, 16, 16
+    hd = d // H
+    ED = 4 * hd
+    proj_flops_tok = 5 * 2 * d * d + H * 2 * (hd * 2 * ED + ED * (R + 2 * N) + ED * hd)
+    block_tokens = B * (4 * L + min(25, L) + min(10, L))
+    proj_flops_step = 3.0 * proj_flops_tok * block_tokens
+    pr_ms, pr_n = spans["proj"]
+    proj_tf = proj_flops_step * args.steps / (pr_ms * 1e-3) / 1e12 if pr_ms > 0 else 0.0
+
+    # The step's longest kernel: the backward selective scan (recomputes the states from checkpoints every 4 steps).
+    # Algorithmic bytes of a launch over (B, L') with C = H ED channels: reads xc, z, dyg (C floats per token each),
+    # dbc (H (R + 2 N)), the state checkpoints; writes dxc, dz, the per-group dbc gradient and the per-sequence
+    # parameter partials.
+    C = H * ED
+    gph = int(hmx.lib().hmx_scan_groups_per_head(ED))
+    scan_bytes = 0
+    for Lb in (L, L, L, L, min(25, L), min(10, L)):
+        Tb = B * Lb
+        scan_bytes += 4 * (3 * Tb * C + Tb * H * (R + 2 * N) + int(hmx.lib().hmx_scan_state_floats(B, Lb, C)) +
+                           2 * Tb * C + Tb * H * gph * (R + 2 * N) + B * C * 34)
+    sb_ms, sb_n = spans["scan_bwd"]
+    scan_gbs = scan_bytes * args.steps / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else 0.0
+    scan_traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_scan_bwd_pmc.json")
+    if (B, L, d) == (1024, 100, 64) and os.path.exists(pmc):
+        with open(pmc) as f:
+            scan_traffic = json.load(f).get("hbm_bytes_per_launch")
+
     # HBM roofline of the gather kernel: the step's own gathers are 102,400 ids per launch (26 MB, launch-latency
-    # sized), so the kernel is also timed on 8,388,608 uniform random ids over the same item table.
+    # sized), so the kernel is also timed on 8,388,608 uniform random ids over the same item table -- with fp32 output
+    # (520 B per id at d = 64: index + row read + row write) and with bf16 output (392 B per id moved).
     from generative_recommenders_amd import ops
     n_probe = 1 << 23
     table = model.shared_embeddings.item_emb.weight.detach()
     pid = torch.randint(1, args.items + 1, (n_probe,), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
-    ops.gather_rows(table, pid)
-    hmx.profile_enable(True)
-    hmx.profile_collect("gather_rows")
-    for _ in range(5):
-        ops.gather_rows(table, pid)
-    torch.cuda.synchronize()
-    p_ms, p_n = hmx.profile_collect("gather_rows")
-    hmx.profile_enable(False)
+    probes = {}
+    for tag, fn in (("gather_rows", ops.gather_rows), ("gather_rows_bf16", ops.gather_rows_bf16)):
+        fn(table, pid)
+        hmx.profile_enable(True)
+        hmx.profile_collect(tag)
+        for _ in range(5):
+            fn(table, pid)
+        torch.cuda.synchronize()
+        probes[tag] = hmx.profile_collect(tag)
+        hmx.profile_enable(False)
+    p_ms, p_n = probes["gather_rows"]
+    b_ms, b_n = probes["gather_rows_bf16"]
     probe_bytes = n_probe * (8 + 2 * d * 4)
+    probe_bytes_bf16 = n_probe * (8 + d * 4 + d * 2)
     traffic = None
     pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gather_pmc.json")
     if d == 64 and args.items == 4_000_000 and os.path.exists(pmc):    # counters were collected on this exact launch
         with open(pmc) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")
     gather_gbs = probe_bytes * p_n / (p_ms * 1e-3) / 1e9 if p_ms > 0 else 0.0
+    gather_bf16_gbs = probe_bytes_bf16 * b_n / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0
     del pid
     out = {
         "metric": "user seqs/s hydra3 fwd+bwd", "value": B * world / step_s, "unit": "user seqs/s",
@@ -160,18 +211,42 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                                "gathers per step here (seq, pos), three in the reference",
                    "parallelism": f"dp{world}" if world > 1 else "single GPU"},
         "fwd_bwd_ms": fwd_bwd_ms, "fwd_bwd_seqs_per_s": B * world / (fwd_bwd_ms * 1e-3), "loss": float(loss.item()),
-        "roofline": {"bound": "hbm", "achieved": gather_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": gather_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r01_gather_pmc.json)",
-                     "kernel": "gather_rows_kernel",
-                     "launch": f"{n_probe} uniform random ids over the {args.items + 1} x {d} item table",
-                     "launches": p_n, "avg_launch_ms": p_ms / max(p_n, 1), "algorithmic_bytes_per_launch": probe_bytes},
+        "roofline": {"bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": scan_gbs / HBM_PEAK_GBS, "traffic": scan_traffic,
+                     "traffic_unit": "HBM bytes per launch, mean over the step's six launches (FETCH_SIZE x 2 + WRITE_SIZE, "
+                                     "profiles/r02_scan_bwd_pmc.json)",
+                     "kernel": "scan_bwd_kernel (the step's longest kernel; its pace is set by the exp / fma work of the "
+                               "recomputed recurrence, not by memory)",
+                     "launches": sb_n, "avg_launch_ms": sb_ms / max(sb_n, 1),
+                     "algorithmic_bytes_per_launch": scan_bytes / 6.0},
+        "encoder": {"projection_flops_per_step": proj_flops_step,
+                    "projection_kernels_ms_per_step": pr_ms / args.steps, "projection_launches_per_step": pr_n / args.steps,
+                    "mfma_util_projections": {"achieved_tflops": proj_tf, "frac_of_2500": proj_tf / MFMA_BF16_PEAK_TFLOPS,
+                                              "note": "useful FLOPs / time of the kernels that hold the projections (fused "
+                                                      "block halves incl. their norm / gate / residual work, linear_kernel, "
+                                                      "wgrad_kernel); every product is three bf16 MFMA passes (hi*hi, "
+                                                      "lo*hi, hi*lo) or fp32 MFMA in the weight gradients, so the matrix "
+                                                      "pipes do 3x these FLOPs"},
+                    "scan_fwd_ms_per_step": spans["scan_fwd"][0] / args.steps,
+                    "scan_bwd_ms_per_step": sb_ms / args.steps,
+                    "loss_fwd_ms_per_step": spans["nce_fwd"][0] / args.steps,
+                    "loss_bwd_ms_per_step": spans["nce_bwd"][0] / args.steps},
         "other_kernels": {
+            "gather_rows_kernel probe (hbm)": {
+                "achieved_GBps": gather_gbs, "frac_of_8000": gather_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r01_gather_pmc.json)",
+                "launch": f"{n_probe} uniform random ids over the {args.items + 1} x {d} item table",
+                "launches": p_n, "avg_launch_ms": p_ms / max(p_n, 1), "algorithmic_bytes_per_launch": probe_bytes},
+            "gather_rows_bf16_kernel probe (hbm)": {
+                "achieved_GBps_moved": gather_bf16_gbs,
+                "achieved_GBps_at_the_fp32_accounting": probe_bytes * b_n / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0,
+                "avg_launch_ms": b_ms / max(b_n, 1), "bytes_moved_per_launch": probe_bytes_bf16,
+                "note": "same ids; the output row is bf16, so a launch moves 392 B per id at d = 64 instead of 520"},
             "gather_rows_kernel inside the step": {"ids_per_step": n_ids, "launches": g_n,
                                                    "ms_per_step": g_ms / args.steps},
-            "coarse_bf16_kernel (miner, mfma)": {"achieved_tflops": miner_tf, "frac_of_2500": miner_tf / 2500.0,
-                                                 "ms_per_step": c_ms / args.steps},
-            "segment_sum_kernel (embedding scatter-add, hbm)": {"ms_per_step": s_ms / args.steps, "launches": s_n}},
+            "coarse scoring kernels (miner, mfma)": {"achieved_tflops": miner_tf, "frac_of_2500": miner_tf / 2500.0,
+                                                     "ms_per_step": c_ms / args.steps},
+            "embedding scatter-add (sort + run sums, hbm)": {"ms_per_step": s_ms / args.steps, "launches": s_n}},
     }
     if with_cpu_baseline and rank == 0 and world == 1 and not args.no_cpu_baseline:
         del model, opt
