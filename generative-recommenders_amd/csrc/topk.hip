@@ -1393,8 +1393,8 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             // many queries, every wave walks the whole table: sampled warm-up thresholds (see warm_threshold_kernel)
             const int64_t full_tiles = n_rows / 32;
             // 1/32 of the tiles, but not fewer than 4096 (short item ranges need relatively more: the start-up work
-            // of a pass depends on the absolute number of rows seen), and never more than 1/8
-            const int n_sample = (int)std::min<int64_t>(std::max<int64_t>(full_tiles / 32, std::min<int64_t>(4096, full_tiles / 8)), 8192);
+            // of a pass depends on the absolute number of rows seen), and never more than 1/6 (measured on a 500 K-row range: 1/4 21 ms, 1/6 17 ms, 1/8 18 ms, 1/16 20 ms, 1/32 21 ms)
+            const int n_sample = (int)std::min<int64_t>(std::max<int64_t>(full_tiles / 32, std::min<int64_t>(4096, full_tiles / 6)), 8192);
             if (n_sample >= 64) {
                 const int stride_tiles = (int)((full_tiles - 1) / (n_sample - 1));
                 CoarseParams wp{};
