@@ -84,10 +84,10 @@ int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const i
 
 /* The same scatter-add for callers that cannot allocate device memory or hand over a workspace: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
- * The sort keys, their sorted copies, the run pieces and the sort's temporary storage live in a fixed array of
+ * The sort keys, their sorted copies, the run pieces and the sort's digit counters live in a fixed array of
  * hmx_scatter_add_rows_static_scratch_bytes() (16 MiB) inside the library, one copy per GPU, held until the process
  * ends; the call allocates nothing.  Inputs whose hmx_scatter_add_rows_workspace_bytes(n, n_rows, d) exceeds that
- * size (about 650,000 ids at d = 64) are refused with HMX_ELIMIT and nothing is enqueued.  Result: bit-identical to
+ * size (about 1,000,000 ids at d = 64) are refused with HMX_ELIMIT and nothing is enqueued.  Result: bit-identical to
  * hmx_scatter_add_rows_f32.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
  * (different streams or threads) race; calls on one stream, or on different GPUs, do not. */
 size_t hmx_scatter_add_rows_static_scratch_bytes(void);
