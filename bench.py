@@ -162,7 +162,7 @@ def run_retrieval(args, world, rank):
     my_queries = max(0, min(per_group, args.queries - qgroup * per_group))
     flops_per_step = 2.0 * my_queries * (hi - lo) * d
     achieved = flops_per_step * args.steps / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic("r01_retrieval_pmc.json") if world == 1 else (None, None)
+    traffic, traffic_src = pmc_traffic("r02_retrieval_pmc.json") if world == 1 else (None, None)
     out = {
         "metric": "top-10 queries/s over 4M items", "value": args.queries / step_s, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,

@@ -50,7 +50,7 @@ def cpu_baseline_train(args, seconds_cap=40.0):
     dt = one(B, 3)
     # BASELINE.json configs[0]: encoder forward only (log2feats, eval mode), batch 128, on the same host cores
     model.eval()
-    Be = max(4, min(128, B))
+    Be = max(4, min(128, int(128 * (100 * 64 * 64) / (args.seq_len * args.dim * args.dim))))   # 128 at configs[0]
     be = synth.train_batch(Be, args.seq_len, args.users, args.items, "cpu", seed=3)
     t1 = time.time()
     with torch.no_grad():
