@@ -45,6 +45,8 @@ def parse():
                     help="item-id ranges the table is cut into (0: N, one range per GPU); N / shards ranks "
                          "hold each range and split the queries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-adamw", dest="torch_adamw", action="store_true",
+                    help="train workload: torch's clip_grad_norm_ + fused AdamW instead of the HIP optimizer kernels")
     ap.add_argument("--foreach-adamw", dest="foreach_adamw", action="store_true",
                     help="train workload: PyTorch's default multi-tensor AdamW instead of its fused single-kernel form")
     return ap.parse_args()

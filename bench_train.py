@@ -75,10 +75,17 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     ops_mod.set_fused_table_grad(True)     # table gradients accumulate straight into .grad (same sums, fewer passes)
     from generative_recommenders_amd import enc_ops
     enc_ops.set_direct_param_grad(True)    # weight gradients of the projections: batched launches adding into .grad
-    # main.py:640 builds torch.optim.AdamW(lr, betas=(0.9, 0.98), weight_decay=0.1); fused=True selects PyTorch's
-    # single-kernel implementation of the same update (one pass over the 1.28 GB of tables instead of nine)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1,
-                            fused=not getattr(args, "foreach_adamw", False))
+    # main.py:640 builds torch.optim.AdamW(lr, betas=(0.9, 0.98), weight_decay=0.1) and main.py:709-713 clips the gradient
+    # norm to 1.0 before its step.  Default here: the same update and the same clip on the HIP kernels (one pass for
+    # the norm, one for the update with the clip factor applied inside; optim.HmxAdamW, tested against the torch pair).
+    # --torch-adamw: torch's fused single-kernel AdamW after torch's clip_grad_norm_; --foreach-adamw: torch's default
+    # multi-tensor form.
+    which_opt = "foreach" if getattr(args, "foreach_adamw", False) else ("torch" if getattr(args, "torch_adamw", False) else "hmx")
+    if which_opt == "hmx":
+        from generative_recommenders_amd.optim import HmxAdamW
+        opt = HmxAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1, max_grad_norm=1.0)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1, fused=which_opt == "torch")
     params = list(model.parameters())
     bt = synth.train_batch(B, L, args.users, args.items, dev, seed=99 + rank)
     feat = [[] for _ in range(B)]
@@ -97,14 +104,16 @@ def run_train(args, world, rank, with_cpu_baseline=True):
             timers[-1].record()
         if sync_grads is not None:
             sync_grads()
-        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+        if which_opt != "hmx":
+            torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
         opt.step()
         return loss
 
     for _ in range(max(args.warmup, 1)):
         step()
     hmx.profile_enable(True)
-    TAGS = ("gather_rows", "scatter_segment_sum", "topk_coarse_bf16", "proj", "scan_fwd", "scan_bwd", "nce_fwd", "nce_bwd")
+    TAGS = ("gather_rows", "scatter_segment_sum", "topk_coarse_bf16", "proj", "scan_fwd", "scan_bwd", "nce_fwd", "nce_bwd",
+            "optimizer")
     for tag in TAGS:
         hmx.profile_collect(tag)
     _sync(world)
@@ -204,7 +213,10 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                                 " (configs[4], per GPU)" if (L, d) == (512, 128) else ""),
                    "batch_per_gpu": B, "seq_len": L, "d": d, "users": args.users, "items": args.items,
                    "includes": "zero_grad, forward (encoder + miner top-50 + fused InfoNCE), backward, "
-                               "clip_grad_norm, AdamW (torch.optim.AdamW(fused=True)); table and projection-weight gradients "
+                               "clip_grad_norm + AdamW (" + {"hmx": "optim.HmxAdamW: HIP norm and update kernels, clip factor applied inside the update",
+                                                          "torch": "torch clip_grad_norm_ + torch.optim.AdamW(fused=True)",
+                                                          "foreach": "torch clip_grad_norm_ + torch.optim.AdamW"}[which_opt] +
+                               "); table and projection-weight gradients "
                                "accumulated directly into .grad. Not evaluated: "
                                "the neg_seqs gather + projection and the diversity term, which the reference computes "
                                "and multiplies by its default weights 0.0 (hydra3.py:694-696,711,1146-1149): two row "
@@ -230,7 +242,8 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                     "scan_fwd_ms_per_step": spans["scan_fwd"][0] / args.steps,
                     "scan_bwd_ms_per_step": sb_ms / args.steps,
                     "loss_fwd_ms_per_step": spans["nce_fwd"][0] / args.steps,
-                    "loss_bwd_ms_per_step": spans["nce_bwd"][0] / args.steps},
+                    "loss_bwd_ms_per_step": spans["nce_bwd"][0] / args.steps,
+                    "optimizer_kernels_ms_per_step": spans["optimizer"][0] / args.steps},
         "other_kernels": {
             "gather_rows_kernel probe (hbm)": {
                 "achieved_GBps": gather_gbs, "frac_of_8000": gather_gbs / HBM_PEAK_GBS, "traffic": traffic,

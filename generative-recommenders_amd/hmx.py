@@ -68,6 +68,10 @@ PROTOTYPES = {
     "hmx_nce_bwd_grouped_workspace_bytes": (c_size_t, [I64, I64, I64, I64, I64, I64, I64]),
     "hmx_nce_bwd_grouped_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, F, c_int, P, P, P, P, P, P, P, P, P, I64,
                                         I64, P, c_size_t, P]),
+    "hmx_adamw_chunk_elems": (I64, []),
+    "hmx_grad_norm_workspace_bytes": (c_size_t, [I64]),
+    "hmx_grad_norm_f32": (c_int, [P, P, I64, I64, F, P, c_size_t, P, P]),
+    "hmx_adamw_step_f32": (c_int, [P, P, I64, I64, F, F, F, F, F, I64, P, c_int, P]),
     "hmx_rmsnorm_fwd": (c_int, [P, P, I64, I64, F, P, P, P]),
     "hmx_rmsnorm_bwd_blocks": (I64, [I64]),
     "hmx_rmsnorm_bwd": (c_int, [P, P, P, P, I64, I64, P, P, P]),

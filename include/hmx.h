@@ -381,6 +381,36 @@ int hmx_block_pre_bwd(const hmx_block_args* a, void* stream);
 int hmx_profile_enable(int on);
 int hmx_profile_collect(const char* tag, double* total_ms, int64_t* launches);
 
+/* =================================================================================
+ * Optimizer end of the train step: clip_grad_norm_(max_norm) + torch.optim.AdamW.step() of main.py:640,709-713 over a
+ * list of fp32 tensors.  `tensors` and `chunk_start` are DEVICE arrays: n_tensors descriptors, and n_tensors + 1
+ * ascending int32 offsets with chunk_start[i + 1] - chunk_start[i] = ceil(tensors[i].n / hmx_adamw_chunk_elems()),
+ * total_chunks = chunk_start[n_tensors].  n_tensors <= 1023.
+ * hmx_grad_norm_f32: norm_out[0] = sqrt(sum of squares of all g) (clip_grad_norm_'s total norm, 2-norm),
+ *   norm_out[1] = min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0); both stay on the device.  Deterministic:
+ *   per-chunk partial sums added in a fixed order.
+ * hmx_adamw_step_f32: for every element, with g' = g * (*grad_scale) (grad_scale: device scalar or NULL = 1):
+ *   p *= 1 - lr * weight_decay;  m += (g' - m) * (1 - beta1);  v = beta2 * v + (1 - beta2) * g' * g';
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *   (decoupled weight decay, no amsgrad, not maximize: the reference's configuration).  step counts from 1.
+ *   write_scaled_grads != 0 also stores g' back into g, which is what clip_grad_norm_ leaves in .grad.
+ * ================================================================================= */
+typedef struct {
+    float* p;        /* parameter, updated in place */
+    const float* g;  /* its gradient */
+    float* m;        /* exp_avg */
+    float* v;        /* exp_avg_sq */
+    int64_t n;       /* elements */
+} hmx_adamw_tensor;
+int64_t hmx_adamw_chunk_elems(void);
+size_t hmx_grad_norm_workspace_bytes(int64_t total_chunks);
+int hmx_grad_norm_f32(const hmx_adamw_tensor* tensors, const int32_t* chunk_start, int64_t n_tensors,
+                      int64_t total_chunks, float max_norm, void* workspace, size_t workspace_bytes, float* norm_out,
+                      void* stream);
+int hmx_adamw_step_f32(const hmx_adamw_tensor* tensors, const int32_t* chunk_start, int64_t n_tensors,
+                       int64_t total_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int64_t step, const float* grad_scale, int write_scaled_grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
