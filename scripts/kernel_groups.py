@@ -8,11 +8,11 @@ import sys
 path = sys.argv[1]
 steps = float(sys.argv[2])
 topn = int(sys.argv[3]) if len(sys.argv) > 3 else 25
-f = path if path.endswith(".csv") else glob.glob(os.path.join(path, "*", "*kernel_stats.csv"))[0]
+f = path if path.endswith(".csv") else max(glob.glob(os.path.join(path, "*", "*kernel_stats.csv")), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 groups = {"hmx sort": ["radix_"], "scan": ["scan_"], "linear": ["linear_kernel"], "wgrad": ["wgrad"], "fused block": ["ffn_", "pre_", "post_", "block_"],
           "loss (nce + its run sums)": ["nce_", "WeightedRows"],
-          "optimizer + clip (torch)": ["multi_tensor", "fused_adam", "FusedAdam"], "rocprim sort": ["rocprim", "ROCPRIM"],
+          "optimizer + clip": ["adamw_kernel", "grad_sumsq", "grad_norm_finish", "multi_tensor", "fused_adam", "FusedAdam"], "rocprim sort": ["rocprim", "ROCPRIM"],
           "top-k (miner)": ["coarse", "rescore", "seed_thr", "to_bf16", "warm"], "gather": ["gather_rows"], "conv": ["conv_silu"],
           "scatter (plain rows)": ["PlainRows"], "run joins (both)": ["segment_join_kernel"],
           "pointwise hmx": ["rmsnorm", "binary_", "combine_", "silu_rope", "colsum", "sum_groups", "seq_index", "attn1q"]}
