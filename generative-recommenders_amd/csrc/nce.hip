@@ -172,9 +172,13 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
             const float logit = dot * inv;
             if (slot < C) {
                 if (lc == 0) p.logits[i * C + slot] = logit;
-                const float nm = fmaxf(mx, logit);
-                sm = sm * expf(mx - nm) + walk.copies(vs) * expf(logit - nm);   // exp(-inf) = 0 on the first key
-                mx = nm;
+                // running maximum, rescaled only when it moves (a handful of times per query): one hardware
+                // exponential per key instead of two library ones.  exp(-inf) = 0 on the first key.
+                if (logit > mx) {
+                    sm *= __expf(mx - logit);
+                    mx = logit;
+                }
+                sm += walk.copies(vs) * __expf(logit - mx);
                 if (slot == 0) l0 = logit;
             }
         }
@@ -183,8 +187,8 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
     for (int off = 16; off <= 32; off <<= 1) {
         const float om = __shfl_xor(mx, off), os = __shfl_xor(sm, off);
         const float nm = fmaxf(mx, om);
-        const float a = (mx == -INFINITY) ? 0.f : sm * expf(mx - nm);
-        const float b = (om == -INFINITY) ? 0.f : os * expf(om - nm);
+        const float a = (mx == -INFINITY) ? 0.f : sm * __expf(mx - nm);
+        const float b = (om == -INFINITY) ? 0.f : os * __expf(om - nm);
         sm = a + b;
         mx = nm;
     }
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
             }
             if (slot < C) {
                 // dL / d <qn, keyn>, for all the slots this one stands for
-                const float w = (expf(lg[u] - lse) - (slot == 0 ? 1.f : 0.f)) * g * walk.copies(vs);
+                const float w = (__expf(lg[u] - lse) - (slot == 0 ? 1.f : 0.f)) * g * walk.copies(vs);
                 const float wk = w * inv;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
