@@ -6,8 +6,8 @@
 //   key_1..n_hard  = table[hard_ids[i, .]]      (row gather from the item table, normalised on the fly)
 //   key_rest       = k[inb_idx[i, .]]           (other rows of the same batch)
 //
-// Geometry: one wave per query; 16 lanes x 16 B cover one key row (d <= 256), so a wave handles four keys per
-// step and keeps four steps of row loads in flight.  Row sums use DPP inside a 16-lane row (no LDS).
+// Geometry: one wave per query; four lanes x 16 B x ceil(d / 16) chunks cover one key row (d <= 256), so a wave
+// handles sixteen keys per step.  Row sums use DPP inside a quad (no LDS).
 // Backward: the same traversal yields d q and one coefficient per (query, key); the key gradients are the
 // transposed sparse product  sum_i coef[i, c] * q_i  accumulated per destination row with the deterministic
 // sorted-run sum shared with the embedding backward, followed by the normalisation Jacobian applied once per
@@ -19,7 +19,6 @@ namespace {
 
 using namespace hmx_seg;
 
-constexpr int kStepsInFlight = 4;
 constexpr float kNormEps = 1e-12f;   // F.normalize(eps=1e-12)
 
 struct NceParams {
@@ -121,9 +120,24 @@ __device__ __forceinline__ KeyRef locate_key(const NceParams& p, int64_t i, int 
     return r;
 }
 
+// Geometry of the two key walks: one wave per query; a key row is read by FOUR lanes (a DPP quad), each taking every
+// fourth 16-byte chunk, so a wave handles sixteen keys per step and the per-key bookkeeping (slot -> address, the
+// soft-max update, the coefficient) is issued once per sixteen keys.  NCH = chunks per lane = ceil(d / 16).
+// sum over the 4 lanes of a quad; every lane of the quad receives the total
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    return v;
+}
+template <int NCH>
+struct WalkSteps {
+    static constexpr int value = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);   // steps of 16 keys whose loads are in flight together
+};
+
 template <int NCH>
 __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
-    const int lane = threadIdx.x & 63, grp = lane >> 4, lc = lane & 15;
+    constexpr int kSteps = WalkSteps<NCH>::value;
+    const int lane = threadIdx.x & 63, kg = lane >> 2, sub = lane & 3;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= p.m) return;   // wave-uniform
     const int C = 1 + p.n_hard + p.n_inb;
@@ -132,30 +146,30 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
     const float qs = p.q_inv[i] * p.inv_temp;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        const int c = lc + 16 * ch;
+        const int c = sub + 4 * ch;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < p.cpr) v = reinterpret_cast<const float4*>(p.q)[i * p.cpr + c];
         qv[ch] = make_float4(v.x * qs, v.y * qs, v.z * qs, v.w * qs);
     }
     float mx = -INFINITY, sm = 0.f, l0 = 0.f;
-    for (int c0 = 0; c0 < walk.n_walk; c0 += 4 * kStepsInFlight) {
-        KeyRef ref[kStepsInFlight];
-        float4 v[kStepsInFlight][NCH];
+    for (int c0 = 0; c0 < walk.n_walk; c0 += 16 * kSteps) {
+        KeyRef ref[kSteps];
+        float4 v[kSteps][NCH];
 #pragma unroll
-        for (int u = 0; u < kStepsInFlight; ++u) {
-            const int vs = c0 + 4 * u + grp;
+        for (int u = 0; u < kSteps; ++u) {
+            const int vs = c0 + 16 * u + kg;
             ref[u] = locate_key(p, i, vs < walk.n_walk ? walk.real(vs) : C, C);
         }
 #pragma unroll
-        for (int u = 0; u < kStepsInFlight; ++u)
+        for (int u = 0; u < kSteps; ++u)
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const int c = lc + 16 * ch;
+                const int c = sub + 4 * ch;
                 v[u][ch] = (ref[u].kind != 0 && c < p.cpr) ? ref[u].src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-        for (int u = 0; u < kStepsInFlight; ++u) {
-            const int vs = c0 + 4 * u + grp;
+        for (int u = 0; u < kSteps; ++u) {
+            const int vs = c0 + 16 * u + kg;
             const int slot = vs < walk.n_walk ? walk.real(vs) : C;
             float dot = 0.f, ss = 0.f;
 #pragma unroll
@@ -163,15 +177,15 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
                 dot += dot4(v[u][ch], qv[ch]);
                 ss += dot4(v[u][ch], v[u][ch]);
             }
-            dot = row16_sum(dot);
+            dot = quad_sum(dot);
             float inv = ref[u].inv;
             if (ref[u].kind == 2) {
-                ss = row16_sum(ss);
+                ss = quad_sum(ss);
                 inv = p.normalize ? 1.0f / fmaxf(sqrtf(ss), kNormEps) : 1.0f;
             }
             const float logit = dot * inv;
             if (slot < C) {
-                if (lc == 0) p.logits[i * C + slot] = logit;
+                if (sub == 0) p.logits[i * C + slot] = logit;
                 // running maximum, rescaled only when it moves (a handful of times per query): one hardware
                 // exponential per key instead of two library ones.  exp(-inf) = 0 on the first key.
                 if (logit > mx) {
@@ -183,8 +197,9 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
             }
         }
     }
+    // the sixteen key groups of the wave (every lane of a quad holds the same pair)
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
+    for (int off = 4; off <= 32; off <<= 1) {
         const float om = __shfl_xor(mx, off), os = __shfl_xor(sm, off);
         const float nm = fmaxf(mx, om);
         const float a = (mx == -INFINITY) ? 0.f : sm * __expf(mx - nm);
@@ -202,7 +217,8 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
 
 template <int NCH>
 __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
-    const int lane = threadIdx.x & 63, grp = lane >> 4, lc = lane & 15;
+    constexpr int kSteps = WalkSteps<NCH>::value;
+    const int lane = threadIdx.x & 63, kg = lane >> 2, sub = lane & 3;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= p.m) return;
     const int C = 1 + p.n_hard + p.n_inb;
@@ -211,40 +227,40 @@ __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
     float4 qn[NCH], acc[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-        const int c = lc + 16 * ch;
+        const int c = sub + 4 * ch;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < p.cpr) v = reinterpret_cast<const float4*>(p.q)[i * p.cpr + c];
         qn[ch] = make_float4(v.x * qinv, v.y * qinv, v.z * qinv, v.w * qinv);
         acc[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int c0 = 0; c0 < walk.n_walk; c0 += 4 * kStepsInFlight) {
-        KeyRef ref[kStepsInFlight];
-        float4 v[kStepsInFlight][NCH];
-        float lg[kStepsInFlight];
+    for (int c0 = 0; c0 < walk.n_walk; c0 += 16 * kSteps) {
+        KeyRef ref[kSteps];
+        float4 v[kSteps][NCH];
+        float lg[kSteps];
 #pragma unroll
-        for (int u = 0; u < kStepsInFlight; ++u) {
-            const int vs = c0 + 4 * u + grp;
+        for (int u = 0; u < kSteps; ++u) {
+            const int vs = c0 + 16 * u + kg;
             const int slot = vs < walk.n_walk ? walk.real(vs) : C;
             ref[u] = locate_key(p, i, slot, C);
             lg[u] = slot < C ? p.logits[i * C + slot] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < kStepsInFlight; ++u)
+        for (int u = 0; u < kSteps; ++u)
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
-                const int c = lc + 16 * ch;
+                const int c = sub + 4 * ch;
                 v[u][ch] = (ref[u].kind != 0 && c < p.cpr) ? ref[u].src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-        for (int u = 0; u < kStepsInFlight; ++u) {
-            const int vs = c0 + 4 * u + grp;
+        for (int u = 0; u < kSteps; ++u) {
+            const int vs = c0 + 16 * u + kg;
             const int slot = vs < walk.n_walk ? walk.real(vs) : C;
             float inv = ref[u].inv;
             if (ref[u].kind == 2) {
                 float ss = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) ss += dot4(v[u][ch], v[u][ch]);
-                ss = row16_sum(ss);
+                ss = quad_sum(ss);
                 inv = p.normalize ? 1.0f / fmaxf(sqrtf(ss), kNormEps) : 1.0f;
             }
             if (slot < C) {
@@ -259,14 +275,15 @@ __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
                     acc[ch].w += wk * v[u][ch].w;
                 }
                 // d keyn = w * qn = (w * qinv) * q_i: the coefficient of q_i in the destination row's sum
-                if (lc == 0) p.logits[i * C + slot] = w * qinv;
+                if (sub == 0) p.logits[i * C + slot] = w * qinv;
             }
         }
     }
+    // add the sixteen key groups' partial rows (lanes with the same position in their quad hold the same chunks)
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
+        for (int off = 4; off <= 32; off <<= 1) {
             acc[ch].x += __shfl_xor(acc[ch].x, off);
             acc[ch].y += __shfl_xor(acc[ch].y, off);
             acc[ch].z += __shfl_xor(acc[ch].z, off);
@@ -277,12 +294,12 @@ __global__ __launch_bounds__(256) void nce_bwd_q_kernel(NceParams p) {
     float pr = 0.f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) pr += dot4(qn[ch], acc[ch]);
-    pr = row16_sum(pr);
+    pr = quad_sum(pr);
     if (!p.normalize || qinv >= 1.0f / kNormEps) pr = 0.f;
-    if (grp == 0) {
+    if (kg == 0) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            const int c = lc + 16 * ch;
+            const int c = sub + 4 * ch;
             if (c < p.cpr) {
                 float4 o;
                 o.x = qinv * (acc[ch].x - qn[ch].x * pr);
@@ -483,9 +500,11 @@ static int nce_fwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
     hipLaunchKernelGGL(inv_norm_kernel, dim3(g16), dim3(256), 0, s, q, m, p.cpr, normalize, q_inv);
     hipLaunchKernelGGL(inv_norm_kernel, dim3(g16), dim3(256), 0, s, k, m, p.cpr, normalize, k_inv);
     void* span = hmx_profile_begin("nce_fwd", s);
-    if (p.cpr <= 16) hipLaunchKernelGGL(nce_fwd_kernel<1>, dim3(g4), dim3(256), 0, s, p);
-    else if (p.cpr <= 32) hipLaunchKernelGGL(nce_fwd_kernel<2>, dim3(g4), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(nce_fwd_kernel<4>, dim3(g4), dim3(256), 0, s, p);
+    if (p.cpr <= 4) hipLaunchKernelGGL(nce_fwd_kernel<1>, dim3(g4), dim3(256), 0, s, p);
+    else if (p.cpr <= 8) hipLaunchKernelGGL(nce_fwd_kernel<2>, dim3(g4), dim3(256), 0, s, p);
+    else if (p.cpr <= 16) hipLaunchKernelGGL(nce_fwd_kernel<4>, dim3(g4), dim3(256), 0, s, p);
+    else if (p.cpr <= 32) hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(g4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(g4), dim3(256), 0, s, p);
     hmx_profile_end(span, s);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
@@ -563,9 +582,11 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
     const int C = (int)(1 + n_hard + n_inb);
     const unsigned g16 = (unsigned)hmx_ceil_div(m, 16), g4 = (unsigned)hmx_ceil_div(m, 4);
     void* span = hmx_profile_begin("nce_bwd", s);
-    if (p.cpr <= 16) hipLaunchKernelGGL(nce_bwd_q_kernel<1>, dim3(g4), dim3(256), 0, s, p);
-    else if (p.cpr <= 32) hipLaunchKernelGGL(nce_bwd_q_kernel<2>, dim3(g4), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(nce_bwd_q_kernel<4>, dim3(g4), dim3(256), 0, s, p);
+    if (p.cpr <= 4) hipLaunchKernelGGL(nce_bwd_q_kernel<1>, dim3(g4), dim3(256), 0, s, p);
+    else if (p.cpr <= 8) hipLaunchKernelGGL(nce_bwd_q_kernel<2>, dim3(g4), dim3(256), 0, s, p);
+    else if (p.cpr <= 16) hipLaunchKernelGGL(nce_bwd_q_kernel<4>, dim3(g4), dim3(256), 0, s, p);
+    else if (p.cpr <= 32) hipLaunchKernelGGL(nce_bwd_q_kernel<8>, dim3(g4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(nce_bwd_q_kernel<16>, dim3(g4), dim3(256), 0, s, p);
     HMX_CHECK_LAUNCH();
     // d k: in-batch references (transposed sparse product), then the row's own positive term + normalisation
     if (hipMemsetAsync(dk, 0, (size_t)m * d * sizeof(float), s) != hipSuccess) return HMX_ELAUNCH;
