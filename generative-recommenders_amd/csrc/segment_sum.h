@@ -350,20 +350,28 @@ __global__ __launch_bounds__(kBlock) void segment_sum_balanced_kernel(Src src, c
                     reinterpret_cast<V*>(tail_piece)[b * cpr + c] = acc;
                 }
             };
+            // Keys and values of a trip are requested one trip ahead, AFTER the row loads of the trip before: loads
+            // return in issue order, so waiting for those rows leaves the next keys and values in flight, and a trip
+            // costs one memory round trip (its rows) instead of two (keys / values, then rows).
+            uint32_t key[U], nkey[U];
+            typename Src::Val sv[U], nsv[U];
+            auto fetch_entries = [&](uint32_t(&k)[U], typename Src::Val(&w)[U], int64_t e) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool in = e + u < j1;
+                    k[u] = in ? skeys[e + u] : sentinel;
+                    if (in) w[u] = svals[e + u];
+                }
+            };
+            fetch_entries(key, sv, j0);
             for (int64_t e = j0; e < j1; e += U) {
-                uint32_t key[U];
-                typename Src::Val sv[U];
                 V v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) key[u] = (e + u < j1) ? skeys[e + u] : sentinel;
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (key[u] != sentinel) sv[u] = svals[e + u];
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     v[u] = (key[u] != sentinel)
                                ? src.weigh(sv[u], reinterpret_cast<const V*>(src.rows)[src.row_index(sv[u]) * cpr + c])
                                : vzero<VEC>();
+                if (e + U < j1) fetch_entries(nkey, nsv, e + U);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (e + u >= j1) break;
@@ -374,6 +382,11 @@ __global__ __launch_bounds__(kBlock) void segment_sum_balanced_kernel(Src src, c
                         first_run = false;
                     }
                     if (key[u] != sentinel) vadd(acc, v[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    key[u] = nkey[u];
+                    sv[u] = nsv[u];
                 }
             }
             flush(cur != key_after);
