@@ -69,14 +69,15 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(In in, int64_t n, 
         const int64_t i = base + r * kThreads + tid;
         const bool valid = i < n;
         const uint32_t d = valid ? ((in.key(i) >> shift) & mask) : 0;
-        // one LDS atomic per distinct digit of the wave: lanes holding the same digit elect their lowest lane
-        unsigned long long m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const unsigned long long bb = __ballot((d >> b) & 1);
-            m &= ((d >> b) & 1) ? bb : ~bb;
+        // LDS atomics (integer: the counts do not depend on their order).  A wave whose lanes all hold the same digit
+        // -- runs of equal ids, sentinels -- would serialise 64 ways on one counter, so that case adds once.
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        const unsigned long long bv = __ballot(valid);
+        if (bv != 0 && __ballot(valid && d == d0) == bv && (bv & 1ull)) {     // wave-uniform
+            if (lane == 0) atomicAdd(&h[d0], (unsigned)__popcll(bv));
+        } else if (valid) {
+            atomicAdd(&h[d], 1u);
         }
-        if (valid && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[d], (unsigned)__popcll(m));
     }
     __syncthreads();
     hist[(int64_t)tid * n_tiles + blockIdx.x] = h[tid];
