@@ -211,13 +211,9 @@ def hydra_block(blk, x2, mask1, L, first):
     x_in, z, y2, rstd1 = _BlockPre.apply(x2, drop, mask1, packed, link, L, H, first, eps, blk.norm1.scale,
                                          mhm.linear_layer1.weight, mhm.linear_layer1.bias,
                                          *[m.in_proj.weight for m in heads])
-    one = H == 1
-    cat = (lambda ts: ts[0]) if one else torch.cat
-    xc = E.conv_silu(x_in, cat([m.conv1d.weight.view(ED, 4) for m in heads]), cat([m.conv1d.bias for m in heads]), L)
-    dbc = E.heads_linear(xc, [m.ssm.deltaBC_layer.weight for m in heads])
-    yg = E.selective_scan_gated(xc, z, dbc, cat([m.ssm.dt_proj_layer.weight for m in heads]),
-                                cat([m.ssm.dt_proj_layer.bias for m in heads]), cat([m.ssm.A_log for m in heads]),
-                                cat([m.ssm.D for m in heads]), L, ED, H)
+    conv_w, conv_b, w_dt, b_dt, a_log, dskip = E.head_params(heads)
+    xc = E.conv_silu(x_in, conv_w, conv_b, L)
+    yg = E.proj_scan_gated(xc, z, [m.ssm.deltaBC_layer.weight for m in heads], w_dt, b_dt, a_log, dskip, L, ED, H)
     return _BlockPost.apply(yg, y2, x2, drop, rstd1, mask1, packed, link, L, H, first, blk.norm2.eps, blk.norm1.scale,
                             blk.norm2.scale, mhm.linear_layer2.weight, mhm.linear_layer2.bias, blk.gate.weight,
                             blk.up.weight, blk.down.weight, *[m.out_proj.weight for m in heads])

@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void conv_silu_fwd_vec4_kernel(const float* __
 }
 
 // One block per (sequence, 256-channel slab); walks the sequence backwards with sliding windows.
-// Writes dx (T, C) and per-sequence partials part[b][c][5] = (dw0..dw3, db).
+// Writes dx (T, C) and per-sequence partials part[b] = [dw (C, 4) | db (C)].
 __global__ __launch_bounds__(256) void conv_silu_bwd_kernel(const float* __restrict__ xz, const float* __restrict__ w,
                                                             const float* __restrict__ b, const float* __restrict__ dxc,
                                                             int L, int C, float* __restrict__ dxz,
@@ -780,8 +780,9 @@ __global__ __launch_bounds__(256) void conv_silu_bwd_kernel(const float* __restr
         for (int k = 0; k < 4; ++k) one_step(t - k, g[k], xn[k]);
     }
     for (; t >= 0; --t) one_step(t, dxc[(seq * L + t) * C + c], X(t - 4));
-    float* o = part + (seq * C + c) * 5;
-    o[0] = dw0; o[1] = dw1; o[2] = dw2; o[3] = dw3; o[4] = db;
+    float* o = part + seq * C * 5;
+    *reinterpret_cast<float4*>(o + c * 4) = make_float4(dw0, dw1, dw2, dw3);
+    o[4 * C + c] = db;
 }
 
 // ---------------------------------------------------------------------------- selective scan
@@ -1074,14 +1075,17 @@ __global__ __launch_bounds__(256, 2) void scan_bwd_kernel(ScanBwdParams q) {
         }
     }
     if (live) {
-        float* o = q.par_part + (seq * p.C + c) * 34;
+        // one block per parameter: [dA_log (C, 16) | dW_dt (C, 16) | db_dt (C) | dD (C)]
+        float* o = q.par_part + seq * p.C * 34;
+        float* oa = o + c * kN;
+        float* ow = o + (int64_t)p.C * kN + c * kR;
 #pragma unroll
-        for (int n = 0; n < kN; ++n) {
-            o[n] = dA[n] * A[n];       // A = -exp(A_log)  =>  dA/dA_log = A
-            o[kN + n] = dWd[n];
+        for (int n = 0; n < kN; n += 4) {   // A = -exp(A_log)  =>  dA/dA_log = A
+            *reinterpret_cast<float4*>(oa + n) = make_float4(dA[n] * A[n], dA[n + 1] * A[n + 1], dA[n + 2] * A[n + 2], dA[n + 3] * A[n + 3]);
+            *reinterpret_cast<float4*>(ow + n) = make_float4(dWd[n], dWd[n + 1], dWd[n + 2], dWd[n + 3]);
         }
-        o[32] = dbd;
-        o[33] = dD;
+        o[(int64_t)p.C * 32 + c] = dbd;
+        o[(int64_t)p.C * 33 + c] = dD;
     }
 }
 

@@ -466,8 +466,46 @@ class _ConvSilu(torch.autograd.Function):
         dx, part = torch.empty_like(x), _empty(B, C * 5, like=x)
         hmx.check(_L().hmx_conv_silu_bwd(hmx.ptr(x), hmx.ptr(w), hmx.ptr(b), hmx.ptr(dxc), B, ctx.L, C, hmx.ptr(dx),
                                          hmx.ptr(part), _s()), "hmx_conv_silu_bwd")
-        pg = colsum(part).view(C, 5)
-        return dx, pg[:, :4].contiguous(), pg[:, 4].contiguous(), None
+        pg = colsum(part)                    # [dw (C, 4) | db (C)]
+        return dx, pg[:4 * C].view(C, 4), pg[4 * C:], None
+
+
+class _HeadParams(torch.autograd.Function):
+    """The per-head conv / scan parameters of a block, stacked over heads: one copy launch for all of them; the
+    gradients go back to the heads as slices of the stacked gradients (no launch)."""
+
+    @staticmethod
+    def forward(ctx, H, *params):
+        groups = [params[i:i + H] for i in range(0, len(params), H)]
+        flat = torch.cat([q.detach().reshape(-1) for q in params])
+        outs, at = [], 0
+        for g in groups:
+            n = sum(q.numel() for q in g)
+            outs.append(flat[at:at + n].view(H * g[0].shape[0], *g[0].shape[1:]))
+            at += n
+        ctx.H = H
+        ctx.shapes = [q.shape for q in params]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        H, out = ctx.H, []
+        for gi, g in enumerate(grads):
+            for h in range(H):
+                shape = ctx.shapes[gi * H + h]
+                out.append(None if g is None else g[h * shape[0]:(h + 1) * shape[0]].view(shape))
+        return (None, *out)
+
+
+def head_params(blocks):
+    """(conv weight (C, 4), conv bias (C), W_dt (C, 16), b_dt (C), A_log (C, 16), D (C)) of the heads' MambaBlocks,
+    channels of head h at rows h * ED ... (h + 1) * ED."""
+    per = [[m.conv1d.weight.view(m.conv1d.weight.shape[0], -1) for m in blocks], [m.conv1d.bias for m in blocks],
+           [m.ssm.dt_proj_layer.weight for m in blocks], [m.ssm.dt_proj_layer.bias for m in blocks],
+           [m.ssm.A_log for m in blocks], [m.ssm.D for m in blocks]]
+    if len(blocks) == 1:
+        return tuple(g[0] for g in per)
+    return _HeadParams.apply(len(blocks), *[q for g in per for q in g])
 
 
 def conv_silu(x, w, b, L):
@@ -515,9 +553,84 @@ class _Scan(torch.autograd.Function):
             ddbc = _empty(T, H * P_DBC, like=xc)
             hmx.check(_L().hmx_sum_groups_f32(hmx.ptr(dpart), T * H, gph, P_DBC, hmx.ptr(ddbc), _s()),
                       "hmx_sum_groups_f32")
-        pg = colsum(ppart).view(C, 34)
-        return (dxc, dz, ddbc, pg[:, 16:32].contiguous(), pg[:, 32].contiguous(), pg[:, :16].contiguous(),
-                pg[:, 33].contiguous(), None, None, None)
+        pg = colsum(ppart)                   # [dA_log (C, 16) | dW_dt (C, 16) | db_dt (C) | dD (C)]
+        return (dxc, dz, ddbc, pg[16 * C:32 * C].view(C, 16), pg[32 * C:33 * C], pg[:16 * C].view(C, 16), pg[33 * C:],
+                None, None, None)
+
+
+class _ProjScan(torch.autograd.Function):
+    """deltaBC projection of every head followed by the gated scan, as one node: in the backward pass the projection's
+    input gradient is added into the scan's dxc by the product itself (xc feeds both, autograd would add them)."""
+
+    @staticmethod
+    def forward(ctx, xc, z, Wdt, bdt, A_log, D, L, ED, H, *Wdbc):
+        _need_cuda(xc, z)
+        xc, Wdt, bdt, A_log, D = (_f32c(t) for t in (xc, Wdt, bdt, A_log, D))
+        z = _f32c(z) if z is not None else None
+        ws = [_f32c(q) for q in Wdbc]
+        T, C = xc.shape
+        B = T // L
+        if ED < 32 or ED & (ED - 1) or C != ED * H or len(ws) != H or any(w.shape != (P_DBC, ED) for w in ws):
+            raise hmx.HmxError(f"selective scan needs 4*head_dim to be a power of two >= 32 (got {ED})")
+        dbc = _empty(T, H * P_DBC, like=xc)
+        for h, w in enumerate(ws):
+            _linear_raw(xc.data_ptr() + 4 * h * ED, C, hmx.ptr(w), ED, 1, None, T, P_DBC, ED,
+                        dbc.data_ptr() + 4 * h * P_DBC, H * P_DBC)
+        keep = any(ctx.needs_input_grad)
+        hs = _empty(max(int(_L().hmx_scan_state_floats(B, L, C)), 1), like=xc) if keep else None
+        yg = torch.empty_like(xc)
+        hmx.check(_L().hmx_scan_fwd(hmx.ptr(xc), hmx.ptr(z), hmx.ptr(dbc), hmx.ptr(Wdt), hmx.ptr(bdt), hmx.ptr(A_log),
+                                    hmx.ptr(D), B, L, C, ED, H, hmx.ptr(yg), hmx.ptr(hs), _s()), "hmx_scan_fwd")
+        if keep:
+            ctx.save_for_backward(xc, z, dbc, Wdt, bdt, A_log, D, hs, *ws)
+        ctx.dims = (B, L, C, ED, H)
+        ctx.params = Wdbc
+        return yg
+
+    @staticmethod
+    def backward(ctx, dyg):
+        xc, z, dbc, Wdt, bdt, A_log, D, hs, *ws = ctx.saved_tensors
+        B, L, C, ED, H = ctx.dims
+        T = B * L
+        dyg = _f32c(dyg)
+        gph = _L().hmx_scan_groups_per_head(ED)
+        dxc = torch.empty_like(xc)
+        dz = torch.empty_like(z) if z is not None else None
+        dpart = _empty(T * H, gph, P_DBC, like=xc)
+        ppart = _empty(B, C * 34, like=xc)
+        hmx.check(_L().hmx_scan_bwd(hmx.ptr(xc), hmx.ptr(z), hmx.ptr(dbc), hmx.ptr(Wdt), hmx.ptr(bdt), hmx.ptr(A_log),
+                                    hmx.ptr(D), hmx.ptr(hs), hmx.ptr(dyg), B, L, C, ED, H, hmx.ptr(dxc), hmx.ptr(dz),
+                                    hmx.ptr(dpart), hmx.ptr(ppart), _s()), "hmx_scan_bwd")
+        if gph == 1:
+            ddbc = dpart.view(T, H * P_DBC)
+        else:
+            ddbc = _empty(T, H * P_DBC, like=xc)
+            hmx.check(_L().hmx_sum_groups_f32(hmx.ptr(dpart), T * H, gph, P_DBC, hmx.ptr(ddbc), _s()),
+                      "hmx_sum_groups_f32")
+        dws = []
+        for h, w in enumerate(ws):
+            gp = ddbc.data_ptr() + 4 * h * P_DBC
+            _linear_raw(gp, H * P_DBC, hmx.ptr(w), 1, ED, None, T, ED, P_DBC, dxc.data_ptr() + 4 * h * ED, C,
+                        accumulate=True)
+            if not ctx.needs_input_grad[9 + h]:
+                dws.append(None)
+                continue
+            tw = _param_grad_target(ctx.params[h])
+            if tw is not None:
+                _wgrad_queue.add(ddbc, h * P_DBC, H * P_DBC, xc, h * ED, C, None, T, P_DBC, ED, tw, 0, ED, None, 0)
+                dws.append(None)
+                continue
+            dw = torch.empty_like(w)
+            _wgrad_raw(gp, H * P_DBC, xc.data_ptr() + 4 * h * ED, C, None, T, P_DBC, ED, hmx.ptr(dw), ED, None, xc.device)
+            dws.append(dw)
+        pg = colsum(ppart)                   # [dA_log (C, 16) | dW_dt (C, 16) | db_dt (C) | dD (C)]
+        return (dxc, dz, pg[16 * C:32 * C].view(C, 16), pg[32 * C:33 * C], pg[:16 * C].view(C, 16), pg[33 * C:],
+                None, None, None, *dws)
+
+
+def proj_scan_gated(xc, z, Wdbc, Wdt, bdt, A_log, D, L, ED, H):
+    """selective_scan_gated(xc, z, heads_linear(xc, Wdbc), ...): Wdbc is one (48, ED) deltaBC weight per head."""
+    return _ProjScan.apply(xc, z, Wdt, bdt, A_log, D, L, ED, H, *Wdbc)
 
 
 def selective_scan_gated(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H):

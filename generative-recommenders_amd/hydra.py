@@ -77,14 +77,9 @@ def mamba_heads(blocks, s, L):
     ED, H = blocks[0].dim_inner, len(blocks)
     x_in = E.heads_linear(s, [m.in_proj.weight for m in blocks], rows=(0, ED))
     z = E.heads_linear(s, [m.in_proj.weight for m in blocks], rows=(ED, 2 * ED))
-    one = H == 1
-    cat = (lambda ts: ts[0]) if one else torch.cat
-    xc = E.conv_silu(x_in, cat([m.conv1d.weight.view(ED, D_CONV) for m in blocks]),
-                     cat([m.conv1d.bias for m in blocks]), L)
-    dbc = E.heads_linear(xc, [m.ssm.deltaBC_layer.weight for m in blocks])
-    yg = E.selective_scan_gated(xc, z, dbc, cat([m.ssm.dt_proj_layer.weight for m in blocks]),
-                                cat([m.ssm.dt_proj_layer.bias for m in blocks]), cat([m.ssm.A_log for m in blocks]),
-                                cat([m.ssm.D for m in blocks]), L, ED, H)
+    conv_w, conv_b, w_dt, b_dt, a_log, dskip = E.head_params(blocks)
+    xc = E.conv_silu(x_in, conv_w, conv_b, L)
+    yg = E.proj_scan_gated(xc, z, [m.ssm.deltaBC_layer.weight for m in blocks], w_dt, b_dt, a_log, dskip, L, ED, H)
     return E.heads_linear(yg, [m.out_proj.weight for m in blocks])
 
 
@@ -255,8 +250,31 @@ class HardNegativeMiner:
 
 def _sample_inbatch_indices_no_self(M, rows, T, device):
     """hydra3.py:817-830."""
-    r = torch.randint(0, M - 1, (rows.size(0), T), device=device)
-    return r + (r >= rows.unsqueeze(1)).long()
+    if M - 1 >= 2 ** 31:
+        r = torch.randint(0, M - 1, (rows.size(0), T), device=device)
+        return r + (r >= rows.unsqueeze(1)).long()
+    # drawn as 32-bit integers (the generator yields the same values for either width), widened by the add itself
+    r = torch.randint(0, M - 1, (rows.size(0), T), device=device, dtype=torch.int32)
+    out = torch.empty(rows.size(0), T, dtype=torch.int64, device=device)
+    return torch.add(r, r >= rows.unsqueeze(1).to(torch.int32), out=out)
+
+
+class _TakeRows(torch.autograd.Function):
+    """x2[rows] for distinct, ascending `rows`: the gradient is a row copy into zeros (the general index backward
+    sorts its indices to cope with repeats, which a mask cannot produce)."""
+
+    @staticmethod
+    def forward(ctx, x2, rows):
+        ctx.save_for_backward(rows)
+        ctx.n = x2.shape[0]
+        return x2.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rows,) = ctx.saved_tensors
+        dx = g.new_zeros(ctx.n, g.shape[1])
+        dx.index_copy_(0, rows, g)
+        return dx, None
 
 
 def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=None, hard_negatives=None, T=512,
@@ -272,7 +290,10 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
     step with draws recorded from the reference, whose CPU generator a GPU cannot replay)."""
     device = log_feats.device
     mask = loss_mask.bool()
-    q, k = log_feats[mask], pos_embs[mask]
+    # the masked positions in row-major order, found once (boolean indexing would search the mask per tensor)
+    rows = mask.reshape(-1).nonzero().flatten()
+    d = log_feats.shape[-1]
+    q, k = _TakeRows.apply(log_feats.reshape(-1, d), rows), _TakeRows.apply(pos_embs.reshape(-1, d), rows)
     M = q.shape[0]
     if M == 0:
         return torch.tensor(0.0, device=device, requires_grad=True)
@@ -284,7 +305,10 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
     hard_ids = None
     hard_groups = None
     if hard_negatives is not None and num_hard > 0:                      # hydra3.py:905-919
-        ch = hard_negatives[mask]
+        if hard_negatives.stride(1) == 0:         # one list per sequence, broadcast over its positions
+            ch = hard_negatives[:, 0].index_select(0, torch.div(rows, mask.shape[1], rounding_mode="floor"))
+        else:
+            ch = hard_negatives.reshape(-1, hard_negatives.shape[-1]).index_select(0, rows)
         K = ch.shape[1]
         if K >= num_hard:
             ch = torch.gather(ch, 1, torch.randint(0, K, (M, num_hard), device=device))

@@ -284,7 +284,7 @@ int hmx_seq_index(const int64_t* ids, const int64_t* ts, int64_t T, int64_t L, i
 
 /* Causal depthwise conv (kernel 4) + bias + SiLU over x (T, C), weights w (C, 4), b (C)
  * (nn.Conv1d at hydra3.py:243-250 with the slice at :267, SiLU at :269).  Backward writes dx and
- * per-sequence partials part (B, C, 5) = (dw0..dw3, db); their sums over B are the parameter gradients. */
+ * per-sequence partials part (B, 5 C) = [dw (C, 4) | db (C)]; their sums over B are the parameter gradients. */
 int hmx_conv_silu_fwd(const float* x, const float* w, const float* b, int64_t T, int64_t L, int64_t C, float* xc,
                       void* stream);
 int hmx_conv_silu_bwd(const float* x, const float* w, const float* b, const float* dxc, int64_t B, int64_t L,
@@ -316,7 +316,7 @@ int hmx_pscan_bwd(const float* A, const float* H, const float* dH, int64_t B, in
  * order: opaque to callers, to be handed to hmx_scan_bwd unchanged; the backward pass recomputes the states in
  * between instead of reading them back).  Backward writes dxc, dz, per-group partials of d(dbc)
  * shaped (T, H, hmx_scan_groups_per_head(ED), 48) (sum with hmx_sum_groups_f32) and per-sequence
- * parameter partials par_part (B, C, 34) = [dA_log(16) | dW_dt(16) | db_dt | dD]. */
+ * parameter partials par_part (B, 34 C) = [dA_log (C, 16) | dW_dt (C, 16) | db_dt (C) | dD (C)]. */
 int64_t hmx_scan_state_floats(int64_t B, int64_t L, int64_t C);
 int hmx_scan_fwd(const float* xc, const float* z, const float* dbc, const float* Wdt, const float* bdt,
                  const float* A_log, const float* D, int64_t B, int64_t L, int64_t C, int64_t ED, int64_t H, float* yg,
