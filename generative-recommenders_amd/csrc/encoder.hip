@@ -707,41 +707,48 @@ __global__ __launch_bounds__(256) void conv_silu_fwd_kernel(const float* __restr
     }
 }
 
-// Same, four channels per thread (16-byte loads and stores); C % 4 == 0 and 16-byte aligned rows.
+// Same, four channels and kConvRun consecutive positions of one sequence per thread (16-byte loads and stores, every
+// input row read by one thread apart from the three before its run); C % 4 == 0 and 16-byte aligned rows.
+constexpr int kConvRun = 8;
 __global__ __launch_bounds__(256) void conv_silu_fwd_vec4_kernel(const float* __restrict__ xz, const float* __restrict__ w,
                                                                  const float* __restrict__ b, int64_t T, int L, int C,
                                                                  float* __restrict__ xc) {
     const int C4 = C / 4;
-    const int64_t n = T * C4;
+    const int runs = (L + kConvRun - 1) / kConvRun;
+    const int64_t n = T / L * runs * C4;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
-        const int64_t t = idx / C4;
-        const int c = 4 * (int)(idx % C4), pos = (int)(t % L);
+        const int c = 4 * (int)(idx % C4);
+        const int64_t sr = idx / C4;
+        const int p0 = (int)(sr % runs) * kConvRun;          // first position of the run
+        const int64_t row0 = sr / runs * L + p0;
         float4 wv[4];   // wv[i] = taps of channel c + i
 #pragma unroll
         for (int i = 0; i < 4; ++i) wv[i] = *reinterpret_cast<const float4*>(w + (c + i) * 4);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int tp = pos - 3 + j;
-            if (tp >= 0) {
-                const float4 x = *reinterpret_cast<const float4*>(xz + (t - 3 + j) * C + c);
-                const float w0 = j == 0 ? wv[0].x : j == 1 ? wv[0].y : j == 2 ? wv[0].z : wv[0].w;
-                const float w1 = j == 0 ? wv[1].x : j == 1 ? wv[1].y : j == 2 ? wv[1].z : wv[1].w;
-                const float w2 = j == 0 ? wv[2].x : j == 1 ? wv[2].y : j == 2 ? wv[2].z : wv[2].w;
-                const float w3 = j == 0 ? wv[3].x : j == 1 ? wv[3].y : j == 2 ? wv[3].z : wv[3].w;
-                acc.x += w0 * x.x;   // same accumulation order per channel as the scalar kernel (j ascending)
-                acc.y += w1 * x.y;
-                acc.z += w2 * x.z;
-                acc.w += w3 * x.w;
-            }
-        }
         const float4 bv = *reinterpret_cast<const float4*>(b + c);
-        float4 o;
-        o.x = silu_(bv.x + acc.x);
-        o.y = silu_(bv.y + acc.y);
-        o.z = silu_(bv.z + acc.z);
-        o.w = silu_(bv.w + acc.w);
-        *reinterpret_cast<float4*>(xc + t * C + c) = o;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 x[kConvRun + 3];   // x[k] = input at position p0 - 3 + k; zero before the sequence start
+#pragma unroll
+        for (int k = 0; k < kConvRun + 3; ++k) {
+            const int pos = p0 - 3 + k;
+            x[k] = (pos >= 0 && pos < L) ? *reinterpret_cast<const float4*>(xz + (row0 - 3 + k) * C + c) : zero;
+        }
+#pragma unroll
+        for (int k = 0; k < kConvRun; ++k) {
+            if (p0 + k >= L) break;
+            // per channel: taps in ascending order from zero, as the scalar kernel adds them (a tap before the
+            // sequence start, skipped there, adds a zero product here: the same sum)
+            float4 acc = zero;
+            acc.x += wv[0].x * x[k].x; acc.y += wv[1].x * x[k].y; acc.z += wv[2].x * x[k].z; acc.w += wv[3].x * x[k].w;
+            acc.x += wv[0].y * x[k + 1].x; acc.y += wv[1].y * x[k + 1].y; acc.z += wv[2].y * x[k + 1].z; acc.w += wv[3].y * x[k + 1].w;
+            acc.x += wv[0].z * x[k + 2].x; acc.y += wv[1].z * x[k + 2].y; acc.z += wv[2].z * x[k + 2].z; acc.w += wv[3].z * x[k + 2].w;
+            acc.x += wv[0].w * x[k + 3].x; acc.y += wv[1].w * x[k + 3].y; acc.z += wv[2].w * x[k + 3].z; acc.w += wv[3].w * x[k + 3].w;
+            float4 o;
+            o.x = silu_(bv.x + acc.x);
+            o.y = silu_(bv.y + acc.y);
+            o.z = silu_(bv.z + acc.z);
+            o.w = silu_(bv.w + acc.w);
+            *reinterpret_cast<float4*>(xc + (row0 + k) * C + c) = o;
+        }
     }
 }
 
@@ -1590,8 +1597,9 @@ extern "C" int hmx_conv_silu_fwd(const float* x, const float* w, const float* b,
     const bool vec = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
                                      reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(xc)) & 15) == 0;
     if (vec)
-        hipLaunchKernelGGL(conv_silu_fwd_vec4_kernel, dim3(grid_for(T * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                           w, b, T, (int)L, (int)C, xc);
+        hipLaunchKernelGGL(conv_silu_fwd_vec4_kernel,
+                           dim3(grid_for(T / L * hmx_ceil_div(L, kConvRun) * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                           x, w, b, T, (int)L, (int)C, xc);
     else
         hipLaunchKernelGGL(conv_silu_fwd_kernel, dim3(grid_for(T * C, 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, T,
                            (int)L, (int)C, xc);
