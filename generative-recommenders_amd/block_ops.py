@@ -194,6 +194,38 @@ class _BlockPost(torch.autograd.Function):
         return (dyg, dy2, None, None, None, None, None, None, None, None, None, None, None) + tuple(g)
 
 
+class drop_pool:
+    """While active, the dropout multipliers of the fused blocks are slices of one buffer drawn by a single launch
+    (n_elems: how many the blocks inside will ask for in total; a block that finds too few left draws its own)."""
+    _active = None
+
+    def __init__(self, n_elems, pdrop, device, enabled=True):
+        self.n, self.p, self.device, self.enabled = int(n_elems), float(pdrop), device, enabled and pdrop > 0.0
+        self.buf, self.at = None, 0
+
+    def __enter__(self):
+        if self.enabled:
+            keep = 1.0 - self.p
+            self.buf = torch.empty(self.n, dtype=torch.float32, device=self.device).bernoulli_(keep).mul_(1.0 / keep)
+            self.prev, drop_pool._active = drop_pool._active, self
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            drop_pool._active = self.prev
+        return False
+
+    @staticmethod
+    def take(T, d, pdrop, device):
+        pool = drop_pool._active
+        n = T * d
+        if pool is not None and pool.p == pdrop and pool.at + n <= pool.n and pool.buf.device == device:
+            out = pool.buf[pool.at:pool.at + n].view(T, d)
+            pool.at += (n + 3) // 4 * 4
+            return out
+        return torch.empty(T, d, dtype=torch.float32, device=device).bernoulli_(1.0 - pdrop).mul_(1.0 / (1.0 - pdrop))
+
+
 def hydra_block(blk, x2, mask1, L, first):
     """One HydraBlockFirst / HydraBlock on the fused halves.  x2 (T, d), mask1 (T) or None -> (T, d)."""
     mhm = blk.multiheadMamba
@@ -206,7 +238,7 @@ def hydra_block(blk, x2, mask1, L, first):
     drop = None
     pdrop = blk.dropout.p
     if blk.training and pdrop > 0.0:
-        drop = torch.empty(T, d, dtype=torch.float32, device=x2.device).bernoulli_(1.0 - pdrop).mul_(1.0 / (1.0 - pdrop))
+        drop = drop_pool.take(T, d, pdrop, x2.device)
     eps = blk.norm1.eps
     x_in, z, y2, rstd1 = _BlockPre.apply(x2, drop, mask1, packed, link, L, H, first, eps, blk.norm1.scale,
                                          mhm.linear_layer1.weight, mhm.linear_layer1.bias,

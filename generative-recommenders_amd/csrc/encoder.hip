@@ -182,17 +182,31 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------- column sums
 // out[c] = sum_r P[r * ld + c], rows summed in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ P, int64_t rows, int64_t cols, int64_t ld,
-                                                     float* __restrict__ out) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ P, int64_t rows, int64_t cols, int64_t ld,
+                                                      float* __restrict__ out) {
+    // sixteen waves share the rows of one 64-column block, eight independent loads in flight per lane
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < cols)
-        for (int64_t r = w; r < rows; r += 4) s += P[r * ld + c];
-    red[w][lane] = s;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    if (c < cols) {
+        int64_t r = w;
+        for (; r + 7 * 16 < rows; r += 128) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += P[(r + 16 * k) * ld + c];
+        }
+        for (; r < rows; r += 16) s[0] += P[r * ld + c];
+    }
+    red[w][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
-    if (w == 0 && c < cols) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (w == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        out[c] = t;
+    }
 }
 
 // Two-stage form for tall inputs: block (cb, r) sums the rows of chunk r for 64 columns into part[r][c]; the second
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 }
 // chunks of rows so that about a thousand blocks run; none when the input is short
 int colsum_chunks(int64_t rows, int64_t cols) {
+    if (rows <= 2048) return 1;   // at most 512 KB per 64-column block: one launch beats two
     const int64_t col_blocks = hmx_ceil_div(cols, 64);
     const int64_t want = std::max<int64_t>(1, 1024 / col_blocks);
     return (int)std::min<int64_t>(want, std::max<int64_t>(1, rows / 64));
@@ -1175,7 +1190,7 @@ extern "C" int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_
         HMX_CHECK_LAUNCH();
         return HMX_OK;
     }
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)hmx_ceil_div(cols, 64)), dim3(256), 0, (hipStream_t)stream, P, rows,
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)hmx_ceil_div(cols, 64)), dim3(1024), 0, (hipStream_t)stream, P, rows,
                        cols, ld, out);
     HMX_CHECK_LAUNCH();
     return HMX_OK;

@@ -435,10 +435,15 @@ class Hydra(nn.Module):
             log_seqs, mask, seq_timestamp = log_seqs[:, cut:], mask[:, cut:], seq_timestamp[:, cut:]
             action_type, dwell_bins = action_type[:, cut:], dwell_bins[:, cut:]
         seqs, pm = self.assemble_inputs(log_seqs, mask, seq_timestamp, action_type, dwell_bins)
-        seqs = self.hydra_first(seqs, padding_mask=pm)
-        for blk in self.hydra:
-            seqs = blk(x=seqs, padding_mask=pm)
-        seqs = self.multi_scale_encoder(seqs, pm)
+        B, L, d = seqs.shape
+        # dropout multipliers of all blocks (full-length ones plus the 10- and 25-token windows) from one draw
+        n_drop = d * B * (L * (2 + len(self.hydra)) + min(10, L) + min(25, L))
+        with block_ops.drop_pool(n_drop, self.args.hydra_dropout_rate, seqs.device,
+                                 enabled=self.training and seqs.is_cuda and FUSED_BLOCKS):
+            seqs = self.hydra_first(seqs, padding_mask=pm)
+            for blk in self.hydra:
+                seqs = blk(x=seqs, padding_mask=pm)
+            seqs = self.multi_scale_encoder(seqs, pm)
         return seqs * pm
 
     def get_user_embedding(self, seq, seq_feat, token_type, seq_timestamp, action_type, dwell_bins):

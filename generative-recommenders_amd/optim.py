@@ -66,16 +66,30 @@ class HmxAdamW(torch.optim.Optimizer):
                       "desc": torch.empty(len(active) * _DESC.itemsize, dtype=torch.uint8, device=dev),
                       "host": np.zeros(len(active), dtype=_DESC)}
             self._tables[gi] = cached
+        # parameters and moments stay where they are; gradients may move between steps (autograd hands over fresh
+        # tensors): only the entries whose pointer changed are checked and rewritten, and the table is uploaded
+        # again only if something did
         host = cached["host"]
-        for i, p in enumerate(active):
-            st = self.state[p]
-            g = p.grad
-            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
-                raise hmx.HmxError("HmxAdamW needs contiguous fp32 gradients on the GPU")
-            host[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
-        # pageable source: the bytes are staged before the call returns, the device write is stream-ordered
-        cached["desc"].copy_(torch.from_numpy(host.view(np.uint8).copy()))
+        gptr = [p.grad.data_ptr() for p in active]
+        pptr = [p.data_ptr() for p in active]
+        if gptr != cached.get("gptr") or pptr != cached.get("pptr"):
+            old_g, old_p = cached.get("gptr"), cached.get("pptr")
+            for i, p in enumerate(active):
+                if old_g is not None and old_g[i] == gptr[i] and old_p[i] == pptr[i]:
+                    continue
+                st = self.state[p]
+                g = p.grad
+                if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
+                    raise hmx.HmxError("HmxAdamW needs contiguous fp32 gradients on the GPU")
+                host[i] = (pptr[i], gptr[i], st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+            cached["gptr"], cached["pptr"] = gptr, pptr
+            # pageable source: the bytes are staged before the call returns, the device write is stream-ordered
+            cached["desc"].copy_(torch.from_numpy(host.view(np.uint8).copy()))
         return cached
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}              # the loaded moments live elsewhere
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -113,8 +127,7 @@ class HmxAdamW(torch.optim.Optimizer):
             self.last_grad_norm = norm
             scale_ptr = norm.data_ptr() + 4
         for group, active, t, step in tables:
-            for p in active:
-                self.state[p]["step"].add_(1)
+            torch._foreach_add_([self.state[p]["step"] for p in active], 1)
             b1, b2 = group["betas"]
             hmx.check(L.hmx_adamw_step_f32(t["desc"].data_ptr(), t["starts"].data_ptr(), len(active), t["chunks"],
                                            float(group["lr"]), float(b1), float(b2), float(group["eps"]),
