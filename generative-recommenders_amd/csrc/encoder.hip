@@ -1175,7 +1175,7 @@ extern "C" int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_
                               size_t workspace_bytes, void* stream) {
     HMX_ENTER();
     if (cols == 0) return HMX_OK;
-    if (!P || !out || rows < 0 || ld < cols) return HMX_EINVAL;
+    if ((!P && rows > 0) || !out || rows < 0 || ld < cols) return HMX_EINVAL;   // no rows: the sums are zero
     const int n = colsum_chunks(rows, cols);
     if (n > 1 && workspace != nullptr) {
         if (workspace_bytes < hmx_colsum_workspace_bytes(rows, cols)) return HMX_EWORKSPACE;

@@ -477,3 +477,82 @@ def test_attn1q_dropout_multiplier():
     G.assert_close(got.cpu(), want.detach(), 2e-5, 2e-5, "out")
     G.assert_close(qg.grad.cpu(), qr.grad, 1e-4, 2e-5, "dq")
     G.assert_close(kvg.grad.cpu(), kvr.grad, 1e-4, 2e-5, "dkv")
+
+
+def test_take_rows_matches_boolean_indexing_forward_and_backward():
+    """Loss rows are taken by a list of distinct row numbers (hydra3.py:871-873 indexes by the boolean mask)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(6, 9, 16, generator=g)
+    mask = torch.rand(6, 9, generator=g) > 0.4
+    xa = x.to(DEV).requires_grad_()
+    xb = x.to(DEV).requires_grad_()
+    rows = mask.to(DEV).reshape(-1).nonzero().flatten()
+    ya = H._TakeRows.apply(xa.reshape(-1, 16), rows)
+    yb = xb[mask.to(DEV)]
+    assert torch.equal(ya, yb)
+    gy = torch.randn(ya.shape, generator=g).to(DEV)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert torch.equal(xa.grad, xb.grad)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 5), (100, 64), (1024, 8704), (2048, 70), (5000, 130), (0, 12)])
+def test_colsum_short_and_tall_inputs(rows, cols):
+    g = torch.Generator().manual_seed(rows + cols)
+    P = torch.randn(rows, cols, generator=g)
+    got = E.colsum(P.to(DEV)).cpu()
+    ref = P.double().sum(0).float()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, rows ** 0.5)
+
+
+@pytest.mark.parametrize("B,L,C", [(3, 1, 8), (2, 7, 12), (2, 8, 8), (3, 9, 256), (2, 100, 64), (1, 17, 6)])
+def test_conv_silu_all_run_lengths(B, L, C):
+    """Causal depthwise conv + SiLU (hydra3.py:243-250, 266-269) for lengths around the eight-position runs, with
+    and without 16-byte rows."""
+    g = torch.Generator().manual_seed(B * 100 + L + C)
+    x = torch.randn(B * L, C, generator=g)
+    w = torch.randn(C, 4, generator=g) * 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    y = E.conv_silu(xd, wd, bd, L)
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    xin = xr.view(B, L, C).transpose(1, 2)                                   # (B, C, L)
+    yr = torch.nn.functional.silu(torch.nn.functional.conv1d(xin, wr.view(C, 1, 4), br, padding=3, groups=C)[..., :L])
+    yr = yr.transpose(1, 2).reshape(B * L, C)
+    close(y, yr, 1e-5, 1e-5, "conv y")
+    gy = torch.randn(B * L, C, generator=g)
+    y.backward(gy.to(DEV))
+    yr.backward(gy)
+    close(xd.grad, xr.grad, 1e-5, 1e-5, "conv dx")
+    close(wd.grad, wr.grad, 1e-4, 1e-4, "conv dw")
+    close(bd.grad, br.grad, 1e-4, 1e-4, "conv db")
+
+
+def test_pooled_dropout_draws_one_buffer_and_keeps_the_rate():
+    from generative_recommenders_amd import block_ops
+    torch.manual_seed(5)
+    model = H.build_model(50, 200, d=64, L=30, dropout=0.25, device=DEV, seed=2).train()
+    from generative_recommenders_amd import synth
+    bt = synth.train_batch(4, 30, 50, 200, DEV, seed=3)
+    taken = []
+    real_take = block_ops.drop_pool.take
+
+    def spy(T, d, p, device):
+        out = real_take(T, d, p, device)
+        taken.append(out)
+        return out
+    block_ops.drop_pool.take = staticmethod(spy)
+    try:
+        loss = model(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, None, None, None, bt["ts"],
+                     bt["act"], bt["dwell"])
+        loss.backward()
+    finally:
+        block_ops.drop_pool.take = staticmethod(real_take)
+    assert torch.isfinite(loss)
+    assert len(taken) == 1 + len(model.hydra) + 3          # first block, the stack, the three windows
+    base = taken[0].untyped_storage().data_ptr()
+    assert all(t.untyped_storage().data_ptr() == base for t in taken), "every block's multipliers come from one draw"
+    allv = torch.cat([t.reshape(-1) for t in taken])
+    keep = (allv > 0).float().mean().item()
+    assert abs(keep - 0.75) < 0.02
+    assert torch.allclose(allv[allv > 0], torch.tensor(1.0 / 0.75, device=DEV))
