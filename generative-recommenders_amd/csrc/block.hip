@@ -63,13 +63,23 @@ __device__ __forceinline__ void tile_frags(const f32x16& a, Frag& f0, Frag& f1) 
     f1 = make_frag(v);
 }
 
-// B fragment of k-step ks straight from a row-major fp32 row: columns 16 ks + 4 h + (0..3) and + 8
-__device__ __forceinline__ Frag row_frag(const float* row, int ks, int h) {
-    const float4 a = *reinterpret_cast<const float4*>(row + 16 * ks + 4 * h);
-    const float4 b = *reinterpret_cast<const float4*>(row + 16 * ks + 8 + 4 * h);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+// B fragment of k-step ks straight from a row-major fp32 row: columns 16 ks + 4 h + (0..3) and + 8.  Load and
+// conversion are separate so that a loop can request several k-steps before it uses the first: with one or two waves
+// per SIMD every load that is waited for alone costs a full memory round trip.
+struct RawFrag {
+    float4 a, b;
+};
+__device__ __forceinline__ RawFrag row_raw(const float* row, int ks, int h) {
+    RawFrag r;
+    r.a = *reinterpret_cast<const float4*>(row + 16 * ks + 4 * h);
+    r.b = *reinterpret_cast<const float4*>(row + 16 * ks + 8 + 4 * h);
+    return r;
+}
+__device__ __forceinline__ Frag raw_frag(const RawFrag& r) {
+    const float v[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
     return make_frag(v);
 }
+constexpr int kRowBatch = 4;   // k-steps requested together (KSe = ED / 16 is a multiple of 8)
 
 // Where a kernel reads packed weights from: the pack buffer in global memory (L2), or -- for the entry range
 // [lo, hi) that the workgroup copied at its start -- LDS.
@@ -365,17 +375,25 @@ __device__ __forceinline__ void out_proj(const BlockParams& p, const WSrc<LDSW>&
     for (int hh = 0; hh < l.H; ++hh) {
         const size_t w = l.wout + hh * l.wout_stride;
 
-        for (int ks = 0; ks < l.KSe; ++ks) {
-            const Frag f = row_frag(ygrow + hh * l.ED, ks, h);
+        for (int ks0 = 0; ks0 < l.KSe; ks0 += kRowBatch) {
+            RawFrag raw[kRowBatch];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh) mma<LDSW>(y1[nt], src, w, nt - hh * l.NTh, l.KSe, ks, f, lane);
+            for (int u = 0; u < kRowBatch; ++u) raw[u] = row_raw(ygrow + hh * l.ED, ks0 + u, h);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kRowBatch; ++u) {
+                const Frag f = raw_frag(raw[u]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh)
+                        mma<LDSW>(y1[nt], src, w, nt - hh * l.NTh, l.KSe, ks0 + u, f, lane);
+            }
         }
     }
 }
 
 template <int NT, bool LDSW>
-__global__ __launch_bounds__(256) void block_post_fwd_kernel(BlockParams p) {
+__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void block_post_fwd_kernel(BlockParams p) {   // d <= 64: two workgroups per CU
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const PackLayout& l = p.lay;
     const WSrc<LDSW> src{p.pk, p.lds_lo, p.lds_hi};
@@ -502,14 +520,21 @@ __device__ __forceinline__ void write_scale_partial(const f32x16 (&acc)[NT], flo
         }
 }
 
+// Waves per workgroup of the backward halves.  Their working set wants more than 256 registers, i.e. one wave per SIMD.
+// Eight waves per workgroup (two per SIMD at 256 registers each, sharing one LDS copy of the weights) were measured
+// at d = 64: 216 / 316 bytes per lane spill to scratch and both halves get slower (post 172 -> 177 us, pre 123 -> 139 us
+// per launch on average), so four it stays.
+__host__ __device__ constexpr int bwd_waves(int /*NT*/) { return 4; }
+
 // ------------------------------------------------------------------ post half, backward
 template <int NT, bool LDSW>
-__global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
+__global__ __launch_bounds__(64 * bwd_waves(NT)) void block_post_bwd_kernel(BlockParams p) {
+    constexpr int WPB = bwd_waves(NT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const PackLayout& l = p.lay;
     const WSrc<LDSW> src{p.pk, p.lds_lo, p.lds_hi};
     if (LDSW) {
-        for (unsigned idx = threadIdx.x; idx < p.lds_hi - p.lds_lo; idx += 256) w_lds[idx] = p.pk[p.lds_lo + idx];
+        for (unsigned idx = threadIdx.x; idx < p.lds_hi - p.lds_lo; idx += 64 * WPB) w_lds[idx] = p.pk[p.lds_lo + idx];
         __syncthreads();
     }
     const int d = 32 * NT, C = l.H * l.ED;
@@ -517,7 +542,7 @@ __global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
     f32x16 dsc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) zero(dsc[nt]);
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         const int64_t t = tile * 32 + i;
         const bool ok = t < p.T;
         const int64_t tt = ok ? t : p.T - 1;
@@ -655,17 +680,18 @@ __global__ __launch_bounds__(256) void block_post_bwd_kernel(BlockParams p) {
             }
         }
     }
-    write_scale_partial<NT>(dsc, p.dscale_part + ((int64_t)blockIdx.x * 4 + wave) * d, lane);
+    write_scale_partial<NT>(dsc, p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
 }
 
 // ------------------------------------------------------------------ pre half, backward
 template <int NT, bool LDSW>
-__global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
+__global__ __launch_bounds__(64 * bwd_waves(NT)) void block_pre_bwd_kernel(BlockParams p) {
+    constexpr int WPB = bwd_waves(NT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const PackLayout& l = p.lay;
     const WSrc<LDSW> src{p.pk, p.lds_lo, p.lds_hi};
     if (LDSW) {
-        for (unsigned idx = threadIdx.x; idx < p.lds_hi - p.lds_lo; idx += 256) w_lds[idx] = p.pk[p.lds_lo + idx];
+        for (unsigned idx = threadIdx.x; idx < p.lds_hi - p.lds_lo; idx += 64 * WPB) w_lds[idx] = p.pk[p.lds_lo + idx];
         __syncthreads();
     }
     const int d = 32 * NT, C = l.H * l.ED;
@@ -673,7 +699,7 @@ __global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
     f32x16 dsc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) zero(dsc[nt]);
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         const int64_t t = tile * 32 + i;
         const bool ok = t < p.T;
         const int64_t tt = ok ? t : p.T - 1;
@@ -691,12 +717,21 @@ __global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
         for (int hh = 0; hh < l.H; ++hh) {
             const size_t w = l.wint + hh * l.wint_stride;
 
-            for (int ks = 0; ks < l.KSz; ++ks) {
-                const float* grow = (ks < l.KSe ? p.dx_in : p.dz) + tt * C + hh * l.ED;
-                const Frag f = row_frag(grow, ks < l.KSe ? ks : ks - l.KSe, h);
+            for (int ks0 = 0; ks0 < l.KSz; ks0 += kRowBatch) {      // a batch lies in dx_in or in dz, never across
+                const float* grow = (ks0 < l.KSe ? p.dx_in : p.dz) + tt * C + hh * l.ED;
+                const int kr = ks0 < l.KSe ? ks0 : ks0 - l.KSe;
+                RawFrag raw[kRowBatch];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh) mma<LDSW>(ds[nt], src, w, nt - hh * l.NTh, l.KSz, ks, f, lane);
+                for (int u = 0; u < kRowBatch; ++u) raw[u] = row_raw(grow, kr + u, h);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < kRowBatch; ++u) {
+                    const Frag f = raw_frag(raw[u]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        if (nt >= hh * l.NTh && nt < (hh + 1) * l.NTh)
+                            mma<LDSW>(ds[nt], src, w, nt - hh * l.NTh, l.KSz, ks0 + u, f, lane);
+                }
             }
         }
         // + RoPE^T(dy2);  dx1 = ds * SiLU'(x1);  s = SiLU(x1)
@@ -769,10 +804,13 @@ __global__ __launch_bounds__(256) void block_pre_bwd_kernel(BlockParams p) {
             if (ok) store_tile(dxv, p.dx + t * d, nt, h);
         }
     }
-    write_scale_partial<NT>(dsc, p.dscale_part + ((int64_t)blockIdx.x * 4 + wave) * d, lane);
+    write_scale_partial<NT>(dsc, p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
 }
 
-inline int block_grid(int64_t T) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(hmx_ceil_div(T, 32), 4), 2048)); }
+// workgroups of a launch whose workgroups hold `waves` waves (one 32-token tile per wave and trip)
+inline int block_grid(int64_t T, int waves = 4) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(hmx_ceil_div(T, 32), waves), 8192 / waves));
+}
 
 bool shape_ok(int64_t d, int64_t H) {
     if (H <= 0 || d <= 0 || d % H) return false;
@@ -786,28 +824,31 @@ constexpr size_t kMaxWeightLds = 128 * 1024;
 // (the copy is paid once per CU: one workgroup per CU walks the token tiles); otherwise weights come from L2.
 // Measured at d = 64: the backward halves (512 registers, one wave per SIMD either way) gain 7-10 % from LDS weights;
 // the forward halves fit two waves per SIMD without the LDS footprint and are faster that way, so they pass lo = hi.
-#define HMX_BLOCK_LAUNCH(KERNEL, NTV, p, T, lo, hi, stream)                                                          \
+#define HMX_BLOCK_LAUNCH(KERNEL, NTV, WAVES, p, T, lo, hi, stream)                                                   \
     do {                                                                                                             \
         const size_t lds_bytes = ((hi) - (lo)) * sizeof(uint4);                                                      \
-        if ((hi) > (lo) && lds_bytes <= kMaxWeightLds) {                                                                            \
+        if ((hi) > (lo) && lds_bytes <= kMaxWeightLds) {                                                             \
             (p).lds_lo = (unsigned)(lo);                                                                             \
             (p).lds_hi = (unsigned)(hi);                                                                             \
             static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<NTV, true>),   \
                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWeightLds); \
             (void)attr_;                                                                                             \
-            hipLaunchKernelGGL((KERNEL<NTV, true>), dim3(std::min(block_grid(T), 256)), dim3(256), lds_bytes, stream, p); \
+            hipLaunchKernelGGL((KERNEL<NTV, true>), dim3(std::min(block_grid(T, WAVES), 256)), dim3(64 * (WAVES)),   \
+                               lds_bytes, stream, p);                                                                \
         } else {                                                                                                     \
             (p).lds_lo = (p).lds_hi = 0;                                                                             \
-            hipLaunchKernelGGL((KERNEL<NTV, false>), dim3(std::min(block_grid(T), 1024)), dim3(256), 0, stream, p); \
+            hipLaunchKernelGGL((KERNEL<NTV, false>), dim3(std::min(block_grid(T, WAVES), 4096 / (WAVES))),           \
+                               dim3(64 * (WAVES)), 0, stream, p);                                                    \
         }                                                                                                            \
     } while (0)
 
-#define HMX_BLOCK_DISPATCH(KERNEL, p, lo, hi, stream)                                                                \
+// BWD: the kernel is a backward half (bwd_waves(NT) waves per workgroup); forward halves have four
+#define HMX_BLOCK_DISPATCH(KERNEL, BWD, p, lo, hi, stream)                                                           \
     switch ((p).lay.NT) {                                                                                            \
-        case 1: HMX_BLOCK_LAUNCH(KERNEL, 1, p, (p).T, lo, hi, stream); break;                                         \
-        case 2: HMX_BLOCK_LAUNCH(KERNEL, 2, p, (p).T, lo, hi, stream); break;                                         \
-        case 3: HMX_BLOCK_LAUNCH(KERNEL, 3, p, (p).T, lo, hi, stream); break;                                         \
-        default: HMX_BLOCK_LAUNCH(KERNEL, 4, p, (p).T, lo, hi, stream); break;                                        \
+        case 1: HMX_BLOCK_LAUNCH(KERNEL, 1, (BWD) ? bwd_waves(1) : 4, p, (p).T, lo, hi, stream); break;              \
+        case 2: HMX_BLOCK_LAUNCH(KERNEL, 2, (BWD) ? bwd_waves(2) : 4, p, (p).T, lo, hi, stream); break;              \
+        case 3: HMX_BLOCK_LAUNCH(KERNEL, 3, (BWD) ? bwd_waves(3) : 4, p, (p).T, lo, hi, stream); break;              \
+        default: HMX_BLOCK_LAUNCH(KERNEL, 4, (BWD) ? bwd_waves(4) : 4, p, (p).T, lo, hi, stream); break;             \
     }
 
 }  // namespace
@@ -820,8 +861,10 @@ extern "C" size_t hmx_block_packed_bytes(int64_t d, int64_t H) {
     return make_layout((int)d, (int)H).total * sizeof(uint4);
 }
 
-// waves of a backward launch (one workgroup per CU at most, four waves each): each writes one row of partials
-extern "C" int64_t hmx_block_scale_partial_rows(int64_t T) { return (int64_t)std::min(block_grid(T), 1024) * 4; }
+// upper bound of the waves of a backward launch (each writes one row of partials): whole workgroups of up to eight
+extern "C" int64_t hmx_block_scale_partial_rows(int64_t T) {
+    return std::min<int64_t>(hmx_ceil_div(hmx_ceil_div(std::max<int64_t>(T, 1), 32), 8) * 8, 4096);
+}
 
 extern "C" int hmx_block_pack_f32(const hmx_block_weights* w, int64_t d, int64_t H, void* packed, void* stream) {
     HMX_ENTER();
@@ -872,7 +915,7 @@ extern "C" int hmx_block_pre_fwd(const hmx_block_args* a, void* stream) {
     if (p.T == 0) return HMX_OK;
     if (!p.x || !p.scale1 || !p.b1 || !p.cs || !p.sn || !p.rstd1 || !p.x_in || !p.z || !p.y2) return HMX_EINVAL;
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
-    HMX_BLOCK_DISPATCH(block_pre_fwd_kernel, p, (size_t)0, (size_t)0, (hipStream_t)stream);
+    HMX_BLOCK_DISPATCH(block_pre_fwd_kernel, false, p, (size_t)0, (size_t)0, (hipStream_t)stream);
     hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
@@ -886,7 +929,7 @@ extern "C" int hmx_block_post_fwd(const hmx_block_args* a, void* stream) {
     if (!p.yg || !p.y2 || !p.x || !p.b2 || !p.scale2 || !p.out || !p.m || !p.rstd2 || (p.first && (!p.rstd1 || !p.scale1)))
         return HMX_EINVAL;
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
-    HMX_BLOCK_DISPATCH(block_post_fwd_kernel, p, (size_t)0, (size_t)0, (hipStream_t)stream);
+    HMX_BLOCK_DISPATCH(block_post_fwd_kernel, false, p, (size_t)0, (size_t)0, (hipStream_t)stream);
     hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
@@ -901,7 +944,7 @@ extern "C" int hmx_block_post_bwd(const hmx_block_args* a, void* stream) {
         !p.du || !p.p || !p.dy1 || !p.dscale_part)
         return HMX_EINVAL;
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
-    HMX_BLOCK_DISPATCH(block_post_bwd_kernel, p, p.lay.wg, p.lay.w2t + pack_entries(p.lay.d, p.lay.d), (hipStream_t)stream);
+    HMX_BLOCK_DISPATCH(block_post_bwd_kernel, true, p, p.lay.wg, p.lay.w2t + pack_entries(p.lay.d, p.lay.d), (hipStream_t)stream);
     hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
@@ -916,7 +959,7 @@ extern "C" int hmx_block_pre_bwd(const hmx_block_args* a, void* stream) {
         !p.dscale_part)
         return HMX_EINVAL;
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
-    HMX_BLOCK_DISPATCH(block_pre_bwd_kernel, p, p.lay.w1, p.lay.wint + p.lay.wint_stride * p.lay.H, (hipStream_t)stream);
+    HMX_BLOCK_DISPATCH(block_pre_bwd_kernel, true, p, p.lay.w1, p.lay.wint + p.lay.wint_stride * p.lay.H, (hipStream_t)stream);
     hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
