@@ -829,6 +829,7 @@ struct ScanParams {
                          // 1 / kCk of the state traffic in both directions.
 };
 
+constexpr float kLog2e = 1.44269504088896341f, kLn2 = 0.693147180559945309f;
 constexpr int kScanChunk = 64;  // time steps of dbc staged per LDS fill (forward)
 constexpr int kCk = 4;          // steps between state checkpoints
 constexpr int kScanChunkBwd = 32;  // backward: dbc rows per LDS fill (a multiple of kCk; leaves room for the state history)
@@ -843,10 +844,10 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
     const int hh = cc / p.ED;
     const int64_t seq = blockIdx.x;
     const int HP = p.H * kP;
-    float A[kN], Wd[kR], h[kN];
+    float A2[kN], Wd[kR], h[kN];   // A2 = A * log2(e): the decay exp(delta A) is one multiply and one v_exp_f32
 #pragma unroll
     for (int n = 0; n < kN; ++n) {
-        A[n] = -__expf(p.A_log[cc * kN + n]);
+        A2[n] = -__expf(p.A_log[cc * kN + n]) * kLog2e;
         Wd[n] = p.Wdt[cc * kR + n];
         h[n] = 0.f;
     }
@@ -873,11 +874,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(ScanParams p) {
 #pragma unroll
             for (int k = 0; k < kR; ++k) dpre += Wd[k] * r[k];
             const float delta = softplus_(dpre + bd);
+            const float dxv = delta * x;
             float y = 0.f;
 #pragma unroll
             for (int n = 0; n < kN; ++n) {
-                const float a = __expf(delta * A[n]);
-                h[n] = a * h[n] + (delta * r[kR + n]) * x;
+                const float a = __builtin_amdgcn_exp2f(delta * A2[n]);
+                h[n] = a * h[n] + dxv * r[kR + n];
                 y += h[n] * r[kR + kN + n];
             }
             const int tl = tc0 + s;   // position in the sequence
@@ -959,10 +961,10 @@ __global__ __launch_bounds__(256, 2) void scan_bwd_kernel(ScanBwdParams q) {
     const int64_t seq = blockIdx.x;
     const int HP = p.H * kP;
     const int n_ck = scan_n_ck(p.L);
-    float A[kN], Wd[kR], carry[kN], dA[kN], dWd[kR];
+    float A2[kN], Wd[kR], carry[kN], dA[kN], dWd[kR];   // A2 = A * log2(e) as in the forward kernel
 #pragma unroll
     for (int n = 0; n < kN; ++n) {
-        A[n] = -__expf(p.A_log[cc * kN + n]);
+        A2[n] = -__expf(p.A_log[cc * kN + n]) * kLog2e;
         Wd[n] = p.Wdt[cc * kR + n];
         carry[n] = 0.f;
         dA[n] = 0.f;
@@ -1027,10 +1029,11 @@ __global__ __launch_bounds__(256, 2) void scan_bwd_kernel(ScanBwdParams q) {
                     for (int k = 0; k < kR; ++k) dpre += Wd[k] * r[k];
                     const float delta = softplus_(dpre + bd);
                     dpre_s[u] = dpre + bd;
+                    const float dxv = delta * x[u];
 #pragma unroll
                     for (int n = 0; n < kN; ++n) {
-                        const float a = __expf(delta * A[n]);
-                        h[n] = a * h[n] + (delta * r[kR + n]) * x[u];
+                        const float a = __builtin_amdgcn_exp2f(delta * A2[n]);
+                        h[n] = a * h[n] + dxv * r[kR + n];
                     }
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4)
@@ -1058,23 +1061,26 @@ __global__ __launch_bounds__(256, 2) void scan_bwd_kernel(ScanBwdParams q) {
                 const float dy = p.xz ? gy[u] * silu_(z[u]) : gy[u];
                 if (p.xz) q.dxz[row * p.C + c] = gy[u] * ypre * silu_grad_(z[u]);
                 dD += dy * x[u];
-                float dx = Dv * dy, ddelta = 0.f;
+                // With gh = g (a h_{t-1}):  dA += delta gh,  d delta = sum_n (A gh + g B x) = ln2 sum A2 gh + x sum g B,
+                // dx = D dy + delta sum g B:  the two sums are shared, A itself is not needed in the loop.
+                const float dxv = delta * x[u];
+                float sgh = 0.f, sgb = 0.f;
                 float vB[kN], vC[kN];
 #pragma unroll
                 for (int n = 0; n < kN; ++n) {
-                    const float a = __expf(delta * A[n]);
+                    const float a = __builtin_amdgcn_exp2f(delta * A2[n]);
                     const float Bn = r[kR + n];
                     const float g = r[kR + kN + n] * dy + carry[n];   // dL/dh_t[n]
                     carry[n] = a * g;
-                    const float bterm = delta * Bn * x[u];
-                    const float hprev_a = hcur[n] - bterm;            // a_t * h_{t-1}
-                    ddelta += g * (A[n] * hprev_a + Bn * x[u]);
-                    dA[n] += g * delta * hprev_a;
-                    dx += g * delta * Bn;
-                    vB[n] = g * delta * x[u];
+                    const float gh = g * (hcur[n] - dxv * Bn);        // g * a_t * h_{t-1}
+                    dA[n] += delta * gh;
+                    sgh += A2[n] * gh;
+                    sgb += g * Bn;
+                    vB[n] = g * dxv;
                     vC[n] = dy * hcur[n];
                 }
-                q.dxc[row * p.C + c] = dx;
+                q.dxc[row * p.C + c] = Dv * dy + delta * sgb;
+                const float ddelta = kLn2 * sgh + x[u] * sgb;
                 const float dd = ddelta * (dpre > 20.f ? 1.f : sigmoid_(dpre));
                 dbd += dd;
                 float vR[kR];
@@ -1102,8 +1108,9 @@ __global__ __launch_bounds__(256, 2) void scan_bwd_kernel(ScanBwdParams q) {
         float* oa = o + c * kN;
         float* ow = o + (int64_t)p.C * kN + c * kR;
 #pragma unroll
-        for (int n = 0; n < kN; n += 4) {   // A = -exp(A_log)  =>  dA/dA_log = A
-            *reinterpret_cast<float4*>(oa + n) = make_float4(dA[n] * A[n], dA[n + 1] * A[n + 1], dA[n + 2] * A[n + 2], dA[n + 3] * A[n + 3]);
+        for (int n = 0; n < kN; n += 4) {   // A = -exp(A_log)  =>  dA/dA_log = A = A2 ln2
+            *reinterpret_cast<float4*>(oa + n) = make_float4(dA[n] * (A2[n] * kLn2), dA[n + 1] * (A2[n + 1] * kLn2),
+                                                             dA[n + 2] * (A2[n + 2] * kLn2), dA[n + 3] * (A2[n + 3] * kLn2));
             *reinterpret_cast<float4*>(ow + n) = make_float4(dWd[n], dWd[n + 1], dWd[n + 2], dWd[n + 3]);
         }
         o[(int64_t)p.C * 32 + c] = dbd;
