@@ -99,6 +99,19 @@ __device__ __forceinline__ void adamw1(float& p, float g, float& m, float& v, co
     p = p - (h.lr / h.bias_correction1) * (m / denom);
 }
 
+// Every element is read once and written once per step and nothing else in the step reads it soon: the streams
+// bypass the caches' retention (nontemporal), which leaves L2 / Infinity Cache to whatever the next kernels need.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ float4 ldnt(const float* base, int64_t i) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base) + i);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stnt(float* base, int64_t i, const float4& v) {
+    f32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(base) + i);
+}
+
 __global__ __launch_bounds__(kThreads) void adamw_kernel(const hmx_adamw_tensor* __restrict__ tensors,
                                                          const int* __restrict__ chunk_start, int n_tensors,
                                                          AdamHyper h, const float* __restrict__ grad_scale,
@@ -124,34 +137,34 @@ __global__ __launch_bounds__(kThreads) void adamw_kernel(const hmx_adamw_tensor*
         for (int64_t i = threadIdx.x; i < n4; i += 2 * kThreads) {
             const int64_t j = i + kThreads;
             const bool two = j < n4;
-            float4 p0 = reinterpret_cast<float4*>(p)[i], g0 = reinterpret_cast<float4*>(g)[i];
-            float4 m0 = reinterpret_cast<float4*>(m)[i], v0 = reinterpret_cast<float4*>(v)[i];
+            float4 p0 = ldnt(p, i), g0 = ldnt(g, i);
+            float4 m0 = ldnt(m, i), v0 = ldnt(v, i);
             float4 p1 = p0, g1 = g0, m1 = m0, v1 = v0;
             if (two) {
-                p1 = reinterpret_cast<float4*>(p)[j];
-                g1 = reinterpret_cast<float4*>(g)[j];
-                m1 = reinterpret_cast<float4*>(m)[j];
-                v1 = reinterpret_cast<float4*>(v)[j];
+                p1 = ldnt(p, j);
+                g1 = ldnt(g, j);
+                m1 = ldnt(m, j);
+                v1 = ldnt(v, j);
             }
             g0.x *= gs; g0.y *= gs; g0.z *= gs; g0.w *= gs;
             adamw1(p0.x, g0.x, m0.x, v0.x, h);
             adamw1(p0.y, g0.y, m0.y, v0.y, h);
             adamw1(p0.z, g0.z, m0.z, v0.z, h);
             adamw1(p0.w, g0.w, m0.w, v0.w, h);
-            reinterpret_cast<float4*>(p)[i] = p0;
-            reinterpret_cast<float4*>(m)[i] = m0;
-            reinterpret_cast<float4*>(v)[i] = v0;
-            if (write_scaled_grads) reinterpret_cast<float4*>(g)[i] = g0;
+            stnt(p, i, p0);
+            stnt(m, i, m0);
+            stnt(v, i, v0);
+            if (write_scaled_grads) stnt(g, i, g0);
             if (two) {
                 g1.x *= gs; g1.y *= gs; g1.z *= gs; g1.w *= gs;
                 adamw1(p1.x, g1.x, m1.x, v1.x, h);
                 adamw1(p1.y, g1.y, m1.y, v1.y, h);
                 adamw1(p1.z, g1.z, m1.z, v1.z, h);
                 adamw1(p1.w, g1.w, m1.w, v1.w, h);
-                reinterpret_cast<float4*>(p)[j] = p1;
-                reinterpret_cast<float4*>(m)[j] = m1;
-                reinterpret_cast<float4*>(v)[j] = v1;
-                if (write_scaled_grads) reinterpret_cast<float4*>(g)[j] = g1;
+                stnt(p, j, p1);
+                stnt(m, j, m1);
+                stnt(v, j, v1);
+                if (write_scaled_grads) stnt(g, j, g1);
             }
         }
         done = n4 << 2;
