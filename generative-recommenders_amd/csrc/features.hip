@@ -1,0 +1,326 @@
+// Row operations of the feature-fusion paths of the embedding module (embedding.py:216-264, 486-611): bag sums of
+// table rows (array features), the pointwise activations between the projections, the gate product of the gated
+// fusion style and LayerNorm (modality encoders, cross-modal fusion).  All HBM-bound streaming kernels: 16-byte
+// lanes, a row is handled by a group of next_pow2(d/4) lanes (bag sums) or by one wave (LayerNorm).
+#include <algorithm>
+
+#include "hmx_common.h"
+#include "profile.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 256 * 16;
+
+__device__ __forceinline__ float4 f4add(const float4& a, const float4& b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// out[r, :] = sum_{a < A} table[ids[r * A + a], :], added in the order of a; ids outside [0, rows) add nothing.
+// VEC = 4: 16-byte columns (cpr = d / 4), VEC = 1: 4-byte columns (cpr = d).
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gather_sum_rows_kernel(const float* __restrict__ table, int64_t rows, int cpr,
+                                                                 int lpr_log2, const int64_t* __restrict__ ids,
+                                                                 int64_t n, int A, float* __restrict__ out) {
+    const int lpr = 1 << lpr_log2;
+    const int lane_c = threadIdx.x & (lpr - 1);
+    const int rows_per_block = kBlock >> lpr_log2;
+    for (int64_t r = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> lpr_log2); r < n;
+         r += (int64_t)gridDim.x * rows_per_block) {
+        const int64_t* bag = ids + r * A;
+        for (int c = lane_c; c < cpr; c += lpr) {
+            if (VEC == 4) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                int a = 0;
+                // two rows requested before the first is added (the adds stay in bag order)
+                for (; a + 1 < A; a += 2) {
+                    const int64_t i0 = bag[a], i1 = bag[a + 1];
+                    const bool ok0 = i0 >= 0 && i0 < rows, ok1 = i1 >= 0 && i1 < rows;
+                    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                    if (ok0) v0 = reinterpret_cast<const float4*>(table)[i0 * cpr + c];
+                    if (ok1) v1 = reinterpret_cast<const float4*>(table)[i1 * cpr + c];
+                    if (ok0) acc = f4add(acc, v0);
+                    if (ok1) acc = f4add(acc, v1);
+                }
+                if (a < A) {
+                    const int64_t i0 = bag[a];
+                    if (i0 >= 0 && i0 < rows) acc = f4add(acc, reinterpret_cast<const float4*>(table)[i0 * cpr + c]);
+                }
+                reinterpret_cast<float4*>(out)[r * cpr + c] = acc;
+            } else {
+                float acc = 0.f;
+                for (int a = 0; a < A; ++a) {
+                    const int64_t i0 = bag[a];
+                    if (i0 >= 0 && i0 < rows) acc += table[i0 * cpr + c];
+                }
+                out[r * cpr + c] = acc;
+            }
+        }
+    }
+}
+
+// ---- pointwise --------------------------------------------------------------------------------
+// mode 0: ReLU (embedding.py:606, :118, :134); mode 1: exact GELU x * Phi(x) (embedding.py:644, :106, :110, :127)
+__device__ __forceinline__ float act1(float x, int mode) {
+    return mode == 0 ? fmaxf(x, 0.f) : 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float act_grad1(float x, int mode) {
+    if (mode == 0) return x > 0.f ? 1.f : 0.f;
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoid1(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <typename F>
+__device__ __forceinline__ float4 map4(const float4& a, F f) { return make_float4(f(a.x), f(a.y), f(a.z), f(a.w)); }
+
+__global__ __launch_bounds__(kBlock) void act_fwd_kernel(const float* __restrict__ x, int64_t n, int mode, int vec,
+                                                         float* __restrict__ out) {
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    if (vec) {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n / 4; i += step)
+            reinterpret_cast<float4*>(out)[i] =
+                map4(reinterpret_cast<const float4*>(x)[i], [mode](float v) { return act1(v, mode); });
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) out[i] = act1(x[i], mode);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         int64_t n, int mode, int vec, float* __restrict__ dx) {
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    if (vec) {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n / 4; i += step) {
+            const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(g)[i];
+            reinterpret_cast<float4*>(dx)[i] =
+                make_float4(b.x * act_grad1(a.x, mode), b.y * act_grad1(a.y, mode), b.z * act_grad1(a.z, mode),
+                            b.w * act_grad1(a.w, mode));
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) dx[i] = g[i] * act_grad1(x[i], mode);
+    }
+}
+
+// out = p * sigmoid(q)   (embedding.py:254-255: a feature's projection times its learned gate)
+__global__ __launch_bounds__(kBlock) void gate_fwd_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                          int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = p[i] * sigmoid1(q[i]);
+}
+__global__ __launch_bounds__(kBlock) void gate_bwd_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                          const float* __restrict__ g, int64_t n, float* __restrict__ dp,
+                                                          float* __restrict__ dq) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float s = sigmoid1(q[i]);
+        dp[i] = g[i] * s;
+        dq[i] = g[i] * p[i] * s * (1.0f - s);
+    }
+}
+
+// ---- LayerNorm (nn.LayerNorm over the last dimension, biased variance, eps inside the root) -----------
+constexpr int kLnMaxCols = 512;               // columns per row
+constexpr int kLnPerLane = kLnMaxCols / 64;   // columns a lane owns: c = lane + 64 j
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, int64_t T, int d, float eps,
+                                                               float* __restrict__ y, float* __restrict__ mean_out,
+                                                               float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t t = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); t < T; t += waves) {
+        float v[kLnPerLane];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < kLnPerLane; ++j) {
+            const int c = lane + 64 * j;
+            v[j] = c < d ? x[t * d + c] : 0.f;
+            s += v[j];
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < kLnPerLane; ++j) {
+            const int c = lane + 64 * j;
+            const float e = c < d ? v[j] - mean : 0.f;
+            q += e * e;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+        for (int j = 0; j < kLnPerLane; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) y[t * d + c] = (v[j] - mean) * rstd * w[c] + b[c];
+        }
+        if (lane == 0) {
+            mean_out[t] = mean;
+            rstd_out[t] = rstd;
+        }
+    }
+}
+
+// dx per row; per-workgroup column partials of dw (first d columns of a partial row) and db (next d columns).
+__global__ __launch_bounds__(kBlock) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ mean_in,
+                                                               const float* __restrict__ rstd_in,
+                                                               const float* __restrict__ g, int64_t T, int d,
+                                                               float* __restrict__ dx, float* __restrict__ part) {
+    __shared__ float red[(kBlock / 64) * 2 * kLnMaxCols];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t waves = (int64_t)gridDim.x * (kBlock / 64);
+    float pw[kLnPerLane], pb[kLnPerLane], wv[kLnPerLane];
+#pragma unroll
+    for (int j = 0; j < kLnPerLane; ++j) {
+        const int c = lane + 64 * j;
+        pw[j] = pb[j] = 0.f;
+        wv[j] = c < d ? w[c] : 0.f;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * (kBlock / 64) + wave; t < T; t += waves) {
+        const float mean = mean_in[t], rstd = rstd_in[t];
+        float xh[kLnPerLane], gw[kLnPerLane];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kLnPerLane; ++j) {
+            const int c = lane + 64 * j;
+            const float gv = c < d ? g[t * d + c] : 0.f;
+            xh[j] = c < d ? (x[t * d + c] - mean) * rstd : 0.f;
+            gw[j] = gv * wv[j];
+            s1 += gw[j];
+            s2 += gw[j] * xh[j];
+            pw[j] += gv * xh[j];
+            pb[j] += gv;
+        }
+        s1 = wave_sum(s1) / (float)d;
+        s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int j = 0; j < kLnPerLane; ++j) {
+            const int c = lane + 64 * j;
+            if (c < d) dx[t * d + c] = rstd * (gw[j] - s1 - xh[j] * s2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kLnPerLane; ++j) {
+        const int c = lane + 64 * j;
+        red[(wave * 2 + 0) * kLnMaxCols + c] = pw[j];
+        red[(wave * 2 + 1) * kLnMaxCols + c] = pb[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += kBlock) {
+        const int which = c >= d, col = which ? c - d : c;
+        float s = 0.f;
+#pragma unroll
+        for (int wv_i = 0; wv_i < kBlock / 64; ++wv_i) s += red[(wv_i * 2 + which) * kLnMaxCols + col];
+        part[(int64_t)blockIdx.x * 2 * d + c] = s;
+    }
+}
+
+int ln_blocks(int64_t T) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(T, kBlock / 64), 512)); }
+
+int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(n, kBlock), kMaxGrid)); }
+
+bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int hmx_gather_sum_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n,
+                                       int64_t bag, float* out, void* stream) {
+    HMX_ENTER();
+    if (n < 0 || d <= 0 || n_rows <= 0 || bag < 0 || bag > (1 << 20)) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!table || !out || (bag > 0 && !ids)) return HMX_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = d % 4 == 0 && aligned16(table, out);
+    const int64_t cpr = vec ? d / 4 : d;
+    int l2 = 0;
+    while ((1 << l2) < cpr && l2 < 6) ++l2;
+    const int64_t rows_per_block = kBlock >> l2;
+    const int grid = (int)std::min<int64_t>(hmx_ceil_div(n, rows_per_block), kMaxGrid);
+    void* span = hmx_profile_begin("gather_sum_rows", s);
+    if (vec)
+        hipLaunchKernelGGL(gather_sum_rows_kernel<4>, dim3(grid), dim3(kBlock), 0, s, table, n_rows, (int)cpr, l2, ids, n,
+                           (int)bag, out);
+    else
+        hipLaunchKernelGGL(gather_sum_rows_kernel<1>, dim3(grid), dim3(kBlock), 0, s, table, n_rows, (int)cpr, l2, ids, n,
+                           (int)bag, out);
+    hmx_profile_end(span, s);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_act_fwd(const float* x, int64_t n, int mode, float* out, void* stream) {
+    HMX_ENTER();
+    if (n < 0 || mode < 0 || mode > 1) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!x || !out) return HMX_EINVAL;
+    const int vec = n % 4 == 0 && aligned16(x, out);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(vec ? n / 4 : n)), dim3(kBlock), 0, (hipStream_t)stream, x, n, mode,
+                       vec, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_act_bwd(const float* x, const float* g, int64_t n, int mode, float* dx, void* stream) {
+    HMX_ENTER();
+    if (n < 0 || mode < 0 || mode > 1) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!x || !g || !dx) return HMX_EINVAL;
+    const int vec = n % 4 == 0 && aligned16(x, g, dx);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(vec ? n / 4 : n)), dim3(kBlock), 0, (hipStream_t)stream, x, g, n,
+                       mode, vec, dx);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_gate_fwd(const float* p, const float* q, int64_t n, float* out, void* stream) {
+    HMX_ENTER();
+    if (n < 0) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!p || !q || !out) return HMX_EINVAL;
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, p, q, n, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_gate_bwd(const float* p, const float* q, const float* g, int64_t n, float* dp, float* dq,
+                            void* stream) {
+    HMX_ENTER();
+    if (n < 0) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!p || !q || !g || !dp || !dq) return HMX_EINVAL;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, p, q, g, n, dp, dq);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int64_t hmx_layernorm_bwd_blocks(int64_t T) { return ln_blocks(T); }
+
+extern "C" int hmx_layernorm_fwd(const float* x, const float* weight, const float* bias, int64_t T, int64_t d, float eps,
+                                 float* y, float* mean, float* rstd, void* stream) {
+    HMX_ENTER();
+    if (T < 0 || d <= 0 || d > kLnMaxCols) return HMX_EINVAL;
+    if (T == 0) return HMX_OK;
+    if (!x || !weight || !bias || !y || !mean || !rstd) return HMX_EINVAL;
+    const int grid = (int)std::min<int64_t>(hmx_ceil_div(T, kBlock / 64), kMaxGrid);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, x, weight, bias, T, (int)d,
+                       eps, y, mean, rstd);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_layernorm_bwd(const float* x, const float* weight, const float* mean, const float* rstd,
+                                 const float* dy, int64_t T, int64_t d, float* dx, float* part, void* stream) {
+    HMX_ENTER();
+    if (T < 0 || d <= 0 || d > kLnMaxCols) return HMX_EINVAL;
+    if (!part) return HMX_EINVAL;
+    if (T > 0 && (!x || !weight || !mean || !rstd || !dy || !dx)) return HMX_EINVAL;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ln_blocks(T)), dim3(kBlock), 0, (hipStream_t)stream, x, weight, mean,
+                       rstd, dy, T, (int)d, dx, part);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}

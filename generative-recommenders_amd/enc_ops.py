@@ -249,22 +249,24 @@ def _wgrad_raw(dy_ptr, ldy, x_ptr, ldx, in_mask, T, N, K, dw_ptr, ldw, db, devic
 
 
 class _Linear(torch.autograd.Function):
-    """y = ((x * in_mask) W[:, :K]^T + b + c1 r1 + c2 r2) * out_mask   (at most one of the masks)."""
+    """y = ((x * in_mask) W[:, col_off:col_off + K]^T + b + c1 r1 + c2 r2) * out_mask   (at most one of the masks)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, in_mask, out_mask, r1, c1, r2, c2):
+    def forward(ctx, x, weight, bias, in_mask, out_mask, r1, c1, r2, c2, col_off=0):
         _need_cuda(x, weight)
         assert in_mask is None or out_mask is None
         x, w = _f32c(x), _f32c(weight)
         T, K = x.shape
         N, ldw = w.shape
-        assert ldw >= K
+        assert ldw >= col_off + K
         r1 = _f32c(r1) if r1 is not None else None
         r2 = _f32c(r2) if r2 is not None else None
         y = _empty(T, N, like=x)
-        _linear_raw(hmx.ptr(x), K, hmx.ptr(w), ldw, 1, bias, T, N, K, hmx.ptr(y), N, r1, c1, r2, c2, in_mask, out_mask)
+        _linear_raw(hmx.ptr(x), K, hmx.ptr(w) + 4 * col_off, ldw, 1, bias, T, N, K, hmx.ptr(y), N, r1, c1, r2, c2,
+                    in_mask, out_mask)
         ctx.save_for_backward(x, w, in_mask, out_mask)
         ctx.c = (c1, c2)
+        ctx.col_off = col_off
         ctx.has_bias = bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         return y
@@ -281,18 +283,19 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = dr1 = dr2 = None
         if need[0]:
             dx = _empty(T, K, like=x)
-            _linear_raw(hmx.ptr(g), N, hmx.ptr(w), 1, ldw, None, T, K, N, hmx.ptr(dx), K, out_mask=in_mask)
+            _linear_raw(hmx.ptr(g), N, hmx.ptr(w) + 4 * ctx.col_off, 1, ldw, None, T, K, N, hmx.ptr(dx), K,
+                        out_mask=in_mask)
         want_db = ctx.has_bias and need[2]
         tw = _param_grad_target(ctx.wparam) if need[1] else None
         tb = _param_grad_target(ctx.bparam) if want_db else None
         if tw is not None and (tb is not None or not want_db):
             # direct mode: queued, added into .grad by a batched launch; nothing is returned to autograd
-            _wgrad_queue.add(g, 0, N, x, 0, K, in_mask, T, N, K, tw, 0, ldw, tb, 0)
+            _wgrad_queue.add(g, 0, N, x, 0, K, in_mask, T, N, K, tw, ctx.col_off, ldw, tb, 0)
             want_db = False
         elif need[1]:
             dw = torch.zeros_like(w) if ldw > K else torch.empty_like(w)
             db = _empty(N, like=x) if want_db else None
-            _wgrad_raw(hmx.ptr(g), N, hmx.ptr(x), K, in_mask, T, N, K, hmx.ptr(dw), ldw, db, x.device)
+            _wgrad_raw(hmx.ptr(g), N, hmx.ptr(x), K, in_mask, T, N, K, hmx.ptr(dw) + 4 * ctx.col_off, ldw, db, x.device)
             want_db = False
         if want_db:              # frozen weight, trainable bias: the bias gradient is the column sum of dy
             db = colsum(g)
@@ -300,12 +303,13 @@ class _Linear(torch.autograd.Function):
             dr1 = g if ctx.c[0] == 1.0 else combine([g], [ctx.c[0]])
         if need[7]:
             dr2 = g if ctx.c[1] == 1.0 else combine([g], [ctx.c[1]])
-        return dx, dw, db, None, None, dr1, None, dr2, None
+        return dx, dw, db, None, None, dr1, None, dr2, None, None
 
 
-def linear(x, weight, bias=None, in_mask=None, out_mask=None, r1=None, c1=0.0, r2=None, c2=0.0):
-    """nn.Linear forward on bf16 MFMA; uses the first x.shape[1] columns of `weight`."""
-    return _Linear.apply(x, weight, bias, in_mask, out_mask, r1, float(c1), r2, float(c2))
+def linear(x, weight, bias=None, in_mask=None, out_mask=None, r1=None, c1=0.0, r2=None, c2=0.0, col_off=0):
+    """nn.Linear forward on bf16 MFMA; uses the x.shape[1] columns of `weight` that start at column `col_off`
+    (a column block of a wider projection: the other columns see no input and get a zero gradient)."""
+    return _Linear.apply(x, weight, bias, in_mask, out_mask, r1, float(c1), r2, float(c2), int(col_off))
 
 
 class _HeadsLinear(torch.autograd.Function):

@@ -1,0 +1,144 @@
+"""torch.autograd wrappers of the feature-fusion row kernels of libhmx.so (csrc/features.hip).
+
+CUDA fp32 tensors only; no CPU fallback.
+"""
+import torch
+
+from . import hmx, ops
+from .enc_ops import _L, _empty, _s, colsum, linear
+from .ops import _f32c, _i64c, _need_cuda
+
+RELU, GELU = 0, 1
+
+
+class _GatherSumRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, ids, padding_idx):
+        _need_cuda(weight, ids)
+        w, idc = _f32c(weight), _i64c(ids)
+        bag = idc.shape[-1]
+        n = idc.numel() // max(bag, 1)
+        out = torch.empty(*idc.shape[:-1], w.shape[1], dtype=torch.float32, device=w.device)
+        hmx.check(_L().hmx_gather_sum_rows_f32(hmx.ptr(w), w.shape[0], w.shape[1], hmx.ptr(idc), n, bag, hmx.ptr(out),
+                                               _s()), "hmx_gather_sum_rows_f32")
+        ctx.save_for_backward(idc)
+        ctx.n_rows, ctx.padding_idx, ctx.param = w.shape[0], -1 if padding_idx is None else padding_idx, weight
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idc,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        bag, d = idc.shape[-1], g.shape[-1]
+        g2 = _f32c(g).view(-1, d)
+        if g2.shape[0] == 0 or bag == 0:
+            acc = ops._into_param_grad(ctx.param)
+            return (None if acc is not None else torch.zeros(ctx.n_rows, d, device=g.device)), None, None
+        # every id of a bag receives the bag's gradient row: rows repeated by the HIP row gather, then the
+        # deterministic scatter-add
+        src = torch.arange(g2.shape[0] * bag, device=g.device, dtype=torch.int64) // max(bag, 1)
+        rows = ops.gather_rows(g2, src)
+        acc = ops._into_param_grad(ctx.param)
+        gw = ops.scatter_add_rows(rows, idc.reshape(-1), ctx.n_rows, ctx.padding_idx, out=acc)
+        return (None if acc is not None else gw), None, None
+
+
+def gather_sum_rows(weight, ids, padding_idx=None):
+    """out[..., :] = sum_a weight[ids[..., a], :] (nn.Embedding followed by .sum over the bag axis)."""
+    return _GatherSumRows.apply(weight, ids, padding_idx)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        _need_cuda(x)
+        x = _f32c(x)
+        out = torch.empty_like(x)
+        hmx.check(_L().hmx_act_fwd(hmx.ptr(x), x.numel(), mode, hmx.ptr(out), _s()), "hmx_act_fwd")
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _f32c(g)
+        dx = torch.empty_like(x)
+        hmx.check(_L().hmx_act_bwd(hmx.ptr(x), hmx.ptr(g), x.numel(), ctx.mode, hmx.ptr(dx), _s()), "hmx_act_bwd")
+        return dx, None
+
+
+def relu(x):
+    return _Act.apply(x, RELU)
+
+
+def gelu(x):
+    return _Act.apply(x, GELU)
+
+
+class _Gate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, q):
+        _need_cuda(p, q)
+        p, q = _f32c(p), _f32c(q)
+        assert p.shape == q.shape
+        out = torch.empty_like(p)
+        hmx.check(_L().hmx_gate_fwd(hmx.ptr(p), hmx.ptr(q), p.numel(), hmx.ptr(out), _s()), "hmx_gate_fwd")
+        ctx.save_for_backward(p, q)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, q = ctx.saved_tensors
+        g = _f32c(g)
+        dp, dq = torch.empty_like(p), torch.empty_like(q)
+        hmx.check(_L().hmx_gate_bwd(hmx.ptr(p), hmx.ptr(q), hmx.ptr(g), p.numel(), hmx.ptr(dp), hmx.ptr(dq), _s()),
+                  "hmx_gate_bwd")
+        return dp, dq
+
+
+def sigmoid_gate(p, q):
+    """p * sigmoid(q)."""
+    return _Gate.apply(p, q)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _need_cuda(x, weight, bias)
+        x, w, b = _f32c(x), _f32c(weight), _f32c(bias)
+        d = x.shape[-1]
+        T = x.numel() // d
+        y, mean, rstd = torch.empty_like(x), _empty(T, like=x), _empty(T, like=x)
+        hmx.check(_L().hmx_layernorm_fwd(hmx.ptr(x), hmx.ptr(w), hmx.ptr(b), T, d, eps, hmx.ptr(y), hmx.ptr(mean),
+                                         hmx.ptr(rstd), _s()), "hmx_layernorm_fwd")
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = _f32c(dy)
+        d = x.shape[-1]
+        T = x.numel() // d
+        nb = _L().hmx_layernorm_bwd_blocks(T)
+        dx, part = torch.empty_like(x), _empty(nb, 2 * d, like=x)
+        hmx.check(_L().hmx_layernorm_bwd(hmx.ptr(x), hmx.ptr(w), hmx.ptr(mean), hmx.ptr(rstd), hmx.ptr(dy), T, d,
+                                         hmx.ptr(dx), hmx.ptr(part), _s()), "hmx_layernorm_bwd")
+        sums = colsum(part)
+        return dx, sums[:d], sums[d:], None
+
+
+def layernorm(x, weight, bias, eps=1e-5):
+    return _LayerNorm.apply(x, weight, bias, eps)
+
+
+def linear_any(x2, weight, bias=None, r1=None, col_off=0, cols=None):
+    """nn.Linear on a (T, K) input through hmx_linear_f32 (K <= 256); a wider input (the raw multimodal item
+    embeddings, 1024 to 4096 columns) is a plain library GEMM and goes to torch's (hipBLASLt)."""
+    K = x2.shape[1]
+    if K <= 256:
+        return linear(x2, weight, bias, r1=r1, c1=1.0 if r1 is not None else 0.0, col_off=col_off)
+    y = torch.nn.functional.linear(x2, weight[:, col_off:col_off + K], bias)
+    return y if r1 is None else y + r1

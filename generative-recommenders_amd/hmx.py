@@ -104,6 +104,14 @@ PROTOTYPES = {
     "hmx_block_post_fwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
     "hmx_block_post_bwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
     "hmx_block_pre_bwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
+    "hmx_gather_sum_rows_f32": (c_int, [P, I64, I64, P, I64, I64, P, P]),
+    "hmx_act_fwd": (c_int, [P, I64, c_int, P, P]),
+    "hmx_act_bwd": (c_int, [P, P, I64, c_int, P, P]),
+    "hmx_gate_fwd": (c_int, [P, P, I64, P, P]),
+    "hmx_gate_bwd": (c_int, [P, P, P, I64, P, P, P]),
+    "hmx_layernorm_bwd_blocks": (I64, [I64]),
+    "hmx_layernorm_fwd": (c_int, [P, P, P, I64, I64, F, P, P, P, P]),
+    "hmx_layernorm_bwd": (c_int, [P, P, P, P, P, I64, I64, P, P, P]),
     "hmx_profile_enable": (c_int, [c_int]),
     "hmx_profile_collect": (c_int, [c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }

@@ -369,7 +369,7 @@ class EnhancedTrainingLoss(nn.Module):
 
 
 class Hydra(nn.Module):
-    """hydra3.py:553-720 (ids-only feature configuration)."""
+    """hydra3.py:553-720."""
 
     def __init__(self, user_num, item_num, feat_statistics, feat_types, args, shared_embeddings=None):
         super().__init__()
@@ -409,18 +409,23 @@ class Hydra(nn.Module):
             return rows
         return E.linear(rows, self.embedding_projection.weight, self.embedding_projection.bias)
 
-    def _project_ids(self, base):
-        """hydra_projection applied to cat[base, 0]: only the first half of the weight's columns contributes."""
-        return E.linear(base, self.hydra_projection.weight, self.hydra_projection.bias)
+    def _project_ids(self, base, feat=None):
+        """hydra_projection applied to cat[base, feat] without building the concatenation: the two halves of the
+        weight's columns are applied to the two inputs (feat None = the zero block of a batch without features)."""
+        y = E.linear(base, self.hydra_projection.weight, self.hydra_projection.bias)
+        if feat is not None:
+            y = E.linear(feat.reshape(-1, feat.shape[-1]), self.hydra_projection.weight, None, r1=y, c1=1.0,
+                         col_off=base.shape[-1])
+        return y
 
-    def assemble_inputs(self, log_seqs, mask, seq_timestamp, action_type, dwell_bins):
+    def assemble_inputs(self, log_seqs, mask, seq_timestamp, action_type, dwell_bins, seq_feature=None):
         se = self.shared_embeddings
         B, L = log_seqs.shape
         T = B * L
         pm, pos, tb = E.seq_index(log_seqs, seq_timestamp, getattr(self.args, 'time_span', 512))
-        base = ops.gather_routed(se.item_emb.weight, se.user_emb.weight, log_seqs.reshape(T), mask.reshape(T))
-        e = E.combine_ad([base, ops.gather_rows(se.pos_emb.weight, pos, 0)], [1.0, 1.0])
-        proj = self._project_ids(e)
+        e, feat = se.embedding_parts(log_seqs.reshape(T), seq_feature if seq_feature is not None else [], mask.reshape(T),
+                                     include_user=True, fusion_style='early', pos_seq=pos)
+        proj = self._project_ids(e, feat)
         t_rows = self._project_small(ops.gather_rows(se.time_span_emb.weight, tb, 0))
         a_rows = self._project_small(ops.gather_rows(se.action_emb.weight, action_type.reshape(T), 0))
         d_rows = self._project_small(ops.gather_rows(se.dwell_time_emb.weight, dwell_bins.reshape(T), 0))
@@ -434,7 +439,11 @@ class Hydra(nn.Module):
             cut = -self.maxlen - 1
             log_seqs, mask, seq_timestamp = log_seqs[:, cut:], mask[:, cut:], seq_timestamp[:, cut:]
             action_type, dwell_bins = action_type[:, cut:], dwell_bins[:, cut:]
-        seqs, pm = self.assemble_inputs(log_seqs, mask, seq_timestamp, action_type, dwell_bins)
+            if isinstance(seq_feature, dict):
+                seq_feature = {k: v[:, cut:] for k, v in seq_feature.items()}
+            else:
+                seq_feature = [f[cut:] for f in seq_feature]
+        seqs, pm = self.assemble_inputs(log_seqs, mask, seq_timestamp, action_type, dwell_bins, seq_feature)
         B, L, d = seqs.shape
         # dropout multipliers of all blocks (full-length ones plus the 10- and 25-token windows) from one draw
         n_drop = d * B * (L * (2 + len(self.hydra)) + min(10, L) + min(25, L))
@@ -474,10 +483,12 @@ class Hydra(nn.Module):
         se = self.shared_embeddings
         item_table = se.item_emb.weight
         B, L = pos_seqs.shape
-        pos_embs = self._project_ids(se.item_emb(pos_seqs.reshape(B * L))).view(B, L, -1)
+        pos_embs = self._project_ids(*se.embedding_parts(pos_seqs.reshape(B * L), pos_feature, None, False,
+                                                         'early')).view(B, L, -1)
         neg_embs = None
         if self.enchanced_loss.ranking_loss_weight != 0.0:
-            neg_embs = self._project_ids(se.item_emb(neg_seqs.reshape(B * L))).view(B, L, -1)
+            neg_embs = self._project_ids(*se.embedding_parts(neg_seqs.reshape(B * L), neg_feature, None, False,
+                                                             'early')).view(B, L, -1)
         miner = HardNegativeMiner(self, item_table, top_k=50, prepared=self.prepared_item_table())
         hard = miner.mine_hard_negatives_similarity(log_feats[:, -1, :], positive_items=pos_seqs,
                                                     exclude_items=user_item)

@@ -411,6 +411,39 @@ int hmx_adamw_step_f32(const hmx_adamw_tensor* tensors, const int32_t* chunk_sta
                        int64_t total_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t step, const float* grad_scale, int write_scaled_grads, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Feature-fusion paths of the embedding module (embedding.py:216-264, 486-611).  Sparse features use
+ * hmx_gather_rows_f32, every nn.Linear uses hmx_linear_f32; the calls below are the remaining row operations.
+ * ------------------------------------------------------------------------------- */
+
+/* Array features: out[i, :] = sum_{a < bag} table[ids[i * bag + a], :], added in the order of a
+ * (`self.sparse_emb[k](tensor_feature).sum(2)`, embedding.py:247, :527, :584).  ids is (n, bag) int64; an id
+ * outside [0, n_rows) adds nothing.  The backward pass is hmx_scatter_add_rows_f32 over the n * bag ids with each
+ * output-gradient row repeated bag times. */
+int hmx_gather_sum_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n, int64_t bag,
+                            float* out, void* stream);
+
+/* Pointwise activations between the projections.  mode 0: ReLU (F.relu embedding.py:606, nn.ReLU :118, :134);
+ * mode 1: exact GELU x * Phi(x) (F.gelu embedding.py:644, nn.GELU :106, :110, :127).  Backward: dx = g * f'(x). */
+int hmx_act_fwd(const float* x, int64_t n, int mode, float* out, void* stream);
+int hmx_act_bwd(const float* x, const float* g, int64_t n, int mode, float* dx, void* stream);
+
+/* Gated fusion (embedding.py:254-255): out = p * sigmoid(q), p = a feature's projection, q = its gate's linear
+ * output.  Backward: dp = g * sigmoid(q) (the gate's own dependence on p arrives through q's producer),
+ * dq = g * p * sigmoid(q) * (1 - sigmoid(q)). */
+int hmx_gate_fwd(const float* p, const float* q, int64_t n, float* out, void* stream);
+int hmx_gate_bwd(const float* p, const float* q, const float* g, int64_t n, float* dp, float* dq, void* stream);
+
+/* nn.LayerNorm over the last dimension (embedding.py:56, :105, :109, :117, :126, :133): biased variance, eps inside
+ * the root, y = (x - mean) * rstd * weight + bias; d <= 512.  The forward keeps mean and rstd (T each) for the
+ * backward, which writes dx and, per workgroup b < hmx_layernorm_bwd_blocks(T), one partial row
+ * part[b] = [dweight (d) | dbias (d)]; the parameter gradients are the column sums of part (hmx_colsum_f32). */
+int64_t hmx_layernorm_bwd_blocks(int64_t T);
+int hmx_layernorm_fwd(const float* x, const float* weight, const float* bias, int64_t T, int64_t d, float eps, float* y,
+                      float* mean, float* rstd, void* stream);
+int hmx_layernorm_bwd(const float* x, const float* weight, const float* mean, const float* rstd, const float* dy,
+                      int64_t T, int64_t d, float* dx, float* part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

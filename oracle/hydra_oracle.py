@@ -244,12 +244,55 @@ class AdaptiveHardNegativeSampler(nn.Module):
 # ----------------------------------------------------------------------------
 # A1: tables + routed gather   (embedding.py:157-164, 429-454, 613-652)
 # ----------------------------------------------------------------------------
+EMB_DIMS = {"81": 32, "82": 1024, "83": 3584, "84": 4096, "85": 3584, "86": 3584}       # embedding.py:279
+
+
+def modality_encoder(input_dim, h, kind):
+    """embedding.py:97-136 as a bare nn.Sequential (registered under `.encoder` by the caller)."""
+    if kind == "visual":
+        layers = [nn.Linear(input_dim, 2 * h), nn.LayerNorm(2 * h), nn.GELU(), nn.Dropout(0.2), nn.Linear(2 * h, h),
+                  nn.LayerNorm(h), nn.GELU(), nn.Linear(h, h)]
+    elif kind == "categorical":
+        layers = [nn.Linear(input_dim, h), nn.LayerNorm(h), nn.ReLU(), nn.Dropout(0.2), nn.Linear(h, h)]
+    else:
+        layers = [nn.Linear(input_dim, h), nn.LayerNorm(h), nn.ReLU(), nn.Linear(h, h)]
+    holder = nn.Module()
+    holder.encoder = nn.Sequential(*layers)
+    return holder
+
+
+class CrossModalFusion(nn.Module):
+    """embedding.py:12-89."""
+
+    def __init__(self, d, n, heads):
+        super().__init__()
+        self.n = n
+        self.cross_attentions = nn.ModuleDict()
+        self.fusion_gates = nn.ModuleList()
+        if n > 1:
+            for i in range(n):
+                self.fusion_gates.append(nn.Sequential(nn.Linear(2 * d, d), nn.Sigmoid()))
+                for j in range(n):
+                    if i != j:
+                        self.cross_attentions[f"{i}_{j}"] = nn.MultiheadAttention(d, heads, dropout=0.3, batch_first=True)
+        self.norm = nn.LayerNorm(d)
+
+    def forward(self, feats):
+        if self.n <= 1:
+            return feats[0] if feats else None
+        out = 0
+        for i, src in enumerate(feats):
+            got = [self.cross_attentions[f"{i}_{j}"](src, tgt, tgt)[0] for j, tgt in enumerate(feats) if j != i]
+            infl = sum(got) / len(got)
+            out = out + src + self.fusion_gates[i](torch.cat([src, infl], dim=-1)) * infl
+        return self.norm(out)
+
+
 class SharedEmbeddingModule(nn.Module):
-    """ids-only restatement of embedding.py:142-214 (all feature groups empty)."""
+    """embedding.py:142-214, 216-264, 397-652: id tables plus the feature groups in the three fusion styles."""
 
     def __init__(self, user_num, item_num, feat_statistics, feat_types, args, interaction_vocab=None):
         super().__init__()
-        assert all(len(v) == 0 for v in feat_types.values()), "oracle covers the ids-only configuration"
         d = args.shared_hidden_units
         self.args = args
         self.item_emb = nn.Embedding(item_num + 1, d, padding_idx=0)
@@ -258,9 +301,34 @@ class SharedEmbeddingModule(nn.Module):
         self.action_emb = nn.Embedding(args.num_actions + 1, d, padding_idx=0)
         self.time_span_emb = nn.Embedding(getattr(args, 'time_span', 512), d, padding_idx=0)
         self.dwell_time_emb = nn.Embedding(7, d, padding_idx=0)
-        # embedding.py:56,181-185: a LayerNorm exists even with zero modalities
-        self.cross_modal_fusion = nn.Module()
-        self.cross_modal_fusion.norm = nn.LayerNorm(d)
+        ft = lambda k: list(feat_types.get(k, []))
+        self.groups = {      # name -> (kind, keys); insertion order = embedding.py:465-477
+            'item_sparse': ('sparse', ft('item_sparse')), 'item_array': ('array', ft('item_array')),
+            'item_continual': ('continual', ft('item_continual')), 'item_emb': ('dense', ft('item_emb')),
+            'user_sparse': ('sparse', ft('user_sparse')), 'user_array': ('array', ft('user_array')),
+            'user_continual': ('continual', ft('user_continual')),
+            'interaction_sparse': ('sparse', [f'interaction_user_{f}' for f in (interaction_vocab or {})])}
+        vocab = dict(feat_statistics)
+        vocab.update({k: 50000 for k in self.groups['interaction_sparse'][1]})        # embedding.py:267,277
+        self.sparse_emb, self.emb_transform = nn.ModuleDict(), nn.ModuleDict()
+        self.feature_projections, self.feature_gates = nn.ModuleDict(), nn.ModuleDict()
+        for name, (kind, keys) in self.groups.items():
+            for k in keys:
+                if kind in ('sparse', 'array'):
+                    self.sparse_emb[k] = nn.Embedding(vocab[k] + 1, d, padding_idx=0)
+                    self.feature_projections[k] = nn.Linear(d, d)
+                elif kind == 'continual':
+                    self.feature_projections[k] = nn.Linear(1, d)
+                else:
+                    self.emb_transform[k] = modality_encoder(EMB_DIMS[k], d, "categorical" if k == "81" else "visual")
+                self.feature_gates[k] = nn.Sequential(nn.Linear(d, d), nn.Sigmoid())
+        n_dense = len(self.groups['item_emb'][1])
+        self.cross_modal_fusion = CrossModalFusion(d, n_dense, 2)                    # embedding.py:181-185
+        n_item = sum(len(self.groups[g][1]) for g in ('item_sparse', 'item_array', 'item_continual')) + (n_dense > 0)
+        n_user = sum(len(self.groups[g][1]) for g in ('user_sparse', 'user_array', 'user_continual',
+                                                      'interaction_sparse'))
+        self.early_fusion_projection_no_user = nn.Linear(n_item * d, d) if n_item else nn.Identity()
+        self.early_fusion_projection_with_user = nn.Linear((n_item + n_user) * d, d) if n_item + n_user else nn.Identity()
 
     def get_base_embeddings(self, seq, mask=None, include_user=False):
         """embedding.py:429-454."""
@@ -270,13 +338,78 @@ class SharedEmbeddingModule(nn.Module):
             return item_rows * (mask == 1).unsqueeze(-1) + user_rows * (mask == 2).unsqueeze(-1)
         return self.item_emb(seq)
 
+    # one feature of the batch as a tensor (embedding.py:397-427, :511-518)
+    def _tensor(self, feats, kind, k):
+        B, Lm = len(feats), max(len(s) for s in feats)
+        if kind == 'array':
+            present = [[it[k] for it in s if k in it] for s in feats]          # packed to the front (:411-414)
+            A = max([len(v) for s in present for v in s] or [1])
+            t = torch.zeros(B, Lm, A, dtype=torch.long)
+            for b, s in enumerate(present):
+                for j, v in enumerate(s):
+                    t[b, j, :len(v)] = torch.as_tensor(v, dtype=torch.long)
+            return t
+        if kind == 'dense':
+            t = torch.zeros(B, Lm, EMB_DIMS[k])
+        else:
+            t = torch.zeros(B, Lm, dtype=torch.float32 if kind == 'continual' else torch.long)
+        for b, s in enumerate(feats):
+            for l, it in enumerate(s):
+                if k in it:
+                    t[b, l] = torch.as_tensor(it[k], dtype=t.dtype)
+        return t
+
+    def _walk(self, include_user, interaction):
+        names = ['item_sparse', 'item_array', 'item_continual', 'item_emb']
+        names += ['user_sparse', 'user_array', 'user_continual'] if include_user else []
+        names += ['interaction_sparse'] if interaction else []
+        return [(self.groups[n][0], k) for n in names for k in self.groups[n][1]]
+
+    def _raw(self, feats, kind, k):
+        t = self._tensor(feats, kind, k)
+        if kind == 'sparse':
+            return self.sparse_emb[k](t)
+        if kind == 'array':
+            return self.sparse_emb[k](t).sum(2)
+        return t.unsqueeze(2)
+
+    def get_feature_embeddings(self, feats, include_user=False, fusion_style='late'):
+        """embedding.py:456-611, :216-264."""
+        d = self.args.shared_hidden_units
+        if fusion_style != 'gated' and (len(feats) == 0 or len(feats[0]) == 0):
+            return torch.zeros(len(feats), 0, d)
+        B, Lm = len(feats), max(len(s) for s in feats)
+        if fusion_style in ('late', 'gated'):
+            total = torch.zeros(B, Lm, d)
+            for kind, k in self._walk(include_user, True):
+                p = self.emb_transform[k].encoder(self._tensor(feats, kind, k)) if kind == 'dense' \
+                    else self.feature_projections[k](self._raw(feats, kind, k))
+                total = total + (p * self.feature_gates[k](p) if fusion_style == 'gated' else p)
+            return total
+        pieces, dense = [], []
+        for kind, k in self._walk(include_user, include_user):
+            if kind == 'dense':
+                dense.append(self.emb_transform[k].encoder(F.normalize(self._tensor(feats, kind, k), p=2, dim=-1)))
+            elif kind == 'continual':
+                pieces.append(self.feature_projections[k](self._raw(feats, kind, k)))
+            else:
+                pieces.append(self._raw(feats, kind, k))
+        if dense:
+            pieces.append(self.cross_modal_fusion(dense))
+        if not pieces:
+            return torch.zeros(B, Lm, d)
+        proj = self.early_fusion_projection_with_user if include_user else self.early_fusion_projection_no_user
+        return F.relu(proj(torch.cat(pieces, dim=2)))
+
     def get_complete_embeddings(self, seq, feature_array, mask=None, include_user=False,
                                 fusion_style='late', model_style='hstu', pos_seq=None):
-        """embedding.py:613-652 with the ids-only zero feature block (:549-554, :636-639)."""
+        """embedding.py:613-652 (a batch without features gets the zero block of :549-554, :636-639)."""
         base = self.get_base_embeddings(seq, mask, include_user)
         if pos_seq is not None:
             base = base + self.pos_emb(pos_seq)
-        feat = torch.zeros_like(base)
+        feat = self.get_feature_embeddings(feature_array, include_user, fusion_style)
+        if feat.shape[1] == 0 and seq.shape[1] > 0:
+            feat = torch.zeros_like(base)
         if fusion_style == 'late':
             return F.gelu(base + feat)
         return torch.cat([base, feat], dim=2)

@@ -22,6 +22,12 @@ def t(store, key):
     return torch.from_numpy(np.array(a)) if a.shape else torch.tensor(a.item())
 
 
+def js(store, key):
+    """A JSON document stored as a 0-d string array (the reference's list-of-dicts feature format)."""
+    import json
+    return json.loads(str(store[key]))
+
+
 def params(store, prefix):
     head = prefix + "/param/"
     return {k[len(head):]: torch.from_numpy(np.array(v)) for k, v in store.items() if k.startswith(head)}

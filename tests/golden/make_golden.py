@@ -345,11 +345,155 @@ def g11_item_embs(store):
         store["G11/saved/" + name] = arr
 
 
+FEATURE_TYPES_MIX = {"user_sparse": ["103", "104"], "item_sparse": ["100", "117"], "user_array": ["106"],
+                     "item_array": ["150"], "user_continual": ["200"], "item_continual": ["201"],
+                     "item_emb": ["81", "82"]}
+FEATURE_STATS_MIX = {"103": 9, "104": 5, "100": 11, "117": 7, "106": 13, "150": 6}
+FEATURE_TYPES_TRAIN = {"user_sparse": ["103"], "item_sparse": ["100"], "user_array": ["106"], "item_array": [],
+                       "user_continual": [], "item_continual": ["201"], "item_emb": []}
+FEATURE_STATS_TRAIN = {"103": 9, "100": 11, "106": 13}
+EMB_DIMS = {"81": 32, "82": 1024}
+
+
+def synth_features(B, L, ftypes, stats, interaction, seed, lengths=None, p_have=0.8):
+    """The reference's feature format: per sequence a list of per-position dicts {feature id: value}; a feature is
+    present at a position with probability p_have."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for b in range(B):
+        seq = []
+        for _ in range(lengths[b] if lengths else L):
+            it = {}
+            for k in ftypes["user_sparse"] + ftypes["item_sparse"]:
+                if rng.rand() < p_have:
+                    it[k] = int(rng.randint(0, stats[k] + 1))
+            for k in ftypes["user_array"] + ftypes["item_array"]:
+                if rng.rand() < p_have:
+                    it[k] = [int(v) for v in rng.randint(0, stats[k] + 1, size=rng.randint(1, 5))]
+            for k in ftypes["user_continual"] + ftypes["item_continual"]:
+                if rng.rand() < p_have:
+                    it[k] = float(np.float32(rng.randn()))
+            for k in ftypes["item_emb"]:
+                if rng.rand() < p_have:
+                    it[k] = [float(v) for v in rng.randn(EMB_DIMS[k]).astype(np.float32)]
+            for fid in interaction:
+                if rng.rand() < p_have:
+                    it[f"interaction_user_{fid}"] = int(rng.randint(0, 64))
+            seq.append(it)
+        out.append(seq)
+    return out
+
+
+def grads_of(store, prefix, module):
+    for k, p in module.named_parameters():
+        if p.grad is not None:
+            store[f"{prefix}/grad/{k}"] = p.grad.detach().numpy().copy()
+    module.zero_grad(set_to_none=True)
+
+
+def g13_features(store):
+    """Feature-fusion paths of embedding.py (:216-264, :486-652) with every feature group populated, and a full
+    train step of hydra3.py with sparse / array / continual features (no modality encoders: their dropout is not
+    configurable)."""
+    d, L, B, U, I = 16, 6, 3, 12, 40
+    a = make_args(d, L, dropout=0.0)
+    torch.manual_seed(1300)
+    inter = {"7": {}}
+    with quiet():
+        se = ref_emb.SharedEmbeddingModule(U, I, FEATURE_STATS_MIX, FEATURE_TYPES_MIX, a, inter)
+    xavier_(se)
+    se.sparse_emb["interaction_user_7"].weight.data[64:] = 0      # 50,001-row table (embedding.py:267): keeps the file small
+    se.eval()
+    feats = synth_features(B, L, FEATURE_TYPES_MIX, FEATURE_STATS_MIX, inter, seed=1301, lengths=(L, L - 1, L))
+    bt = synth_batch(B, L, U, I, pads=(0, 2, 0), seed=1302)
+    poss = torch.arange(1, L + 1).unsqueeze(0).expand(B, -1) * (bt["seq"] != 0)
+    put_params(store, "G13_mix", se)
+    put(store, "G13_mix", seq=bt["seq"], tok=bt["tok"], poss=poss, U=U, I=I, d=d, L=L,
+        feats_json=np.array(json.dumps(feats)), feat_types_json=np.array(json.dumps(FEATURE_TYPES_MIX)),
+        feat_stats_json=np.array(json.dumps(FEATURE_STATS_MIX)), interaction_json=np.array(json.dumps(inter)))
+    runs = {"early_user": lambda: se.get_complete_embeddings(bt["seq"], feats, mask=bt["tok"], include_user=True,
+                                                             fusion_style="early", model_style="hydra", pos_seq=poss),
+            "early_item": lambda: se.get_complete_embeddings(bt["pos"], feats, mask=bt["tok"], include_user=False,
+                                                             fusion_style="early", model_style="hydra"),
+            "late_item": lambda: se.get_complete_embeddings(bt["pos"], feats, include_user=False, fusion_style="late"),
+            "late_user": lambda: se.get_feature_embeddings(feats, include_user=True, fusion_style="late"),
+            "gated_user": lambda: se.get_feature_embeddings(feats, include_user=True, fusion_style="gated")}
+    put(store, "G13_mix", pos=bt["pos"])
+    for name, fn in runs.items():
+        torch.manual_seed(1310)
+        with quiet():
+            y = fn()
+        G = torch.randn_like(y)
+        y.backward(G)
+        put(store, f"G13_mix/{name}", y=y, G=G)
+        grads_of(store, f"G13_mix/{name}", se)
+    # candidate table with features (embedding.py:686-735) and the saved files (:654-684)
+    with torch.no_grad(), quiet(), contextlib.redirect_stderr(io.StringIO()):
+        item_feats = {i: synth_features(1, 1, FEATURE_TYPES_MIX, FEATURE_STATS_MIX, {}, seed=1400 + i)[0][0]
+                      for i in range(1, I + 1) if i % 3}
+        full = se.get_item_embeddings(item_feats, batch_size=16)
+    put(store, "G13_mix/table", full=full, item_feats_json=np.array(json.dumps({str(k): v for k, v in item_feats.items()})))
+
+    # ---- full train step with features -----------------------------------------------------------
+    d, L, B, U, I = 16, 12, 3, 20, 400
+    a = make_args(d, L, dropout=0.0)
+    torch.manual_seed(1350)
+    with quiet():
+        se = ref_emb.SharedEmbeddingModule(U, I, FEATURE_STATS_TRAIN, FEATURE_TYPES_TRAIN, a, None)
+        m = ref.Hydra(U, I, FEATURE_STATS_TRAIN, FEATURE_TYPES_TRAIN, a, se)
+    for _, p in m.named_parameters():
+        try:
+            torch.nn.init.xavier_normal_(p.data)
+        except Exception:
+            pass
+    for t in (se.pos_emb, se.item_emb, se.user_emb, se.action_emb):
+        t.weight.data[0, :] = 0
+    m.train()
+    bt = synth_batch(B, L, U, I, pads=(0, 2, L - 3), seed=1351)
+    f_seq = synth_features(B, L, FEATURE_TYPES_TRAIN, FEATURE_STATS_TRAIN, {}, seed=1352)
+    f_pos = synth_features(B, L, FEATURE_TYPES_TRAIN, FEATURE_STATS_TRAIN, {}, seed=1353)
+    f_neg = synth_features(B, L, FEATURE_TYPES_TRAIN, FEATURE_STATS_TRAIN, {}, seed=1354)
+    draws, mined = [], []
+    real_randint, real_mine = torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity
+
+    def rec_randint(*a_, **k_):
+        out = real_randint(*a_, **k_)
+        draws.append(out.clone())
+        return out
+
+    def rec_mine(self, *a_, **k_):
+        out = real_mine(self, *a_, **k_)
+        mined.append(out.clone())
+        return out
+
+    torch.manual_seed(4343)
+    torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity = rec_randint, rec_mine
+    try:
+        with quiet():
+            loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, f_seq, f_pos, f_neg,
+                     bt["ts"], bt["act"], bt["dwell"])
+    finally:
+        torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity = real_randint, real_mine
+    loss.backward()
+    prefix = "G13_train"
+    put_params(store, prefix, m)
+    put(store, prefix, loss=loss, rng_seed=4343, U=U, I=I, d=d, L=L, mined_ids=mined[0], n_draws=len(draws),
+        f_seq_json=np.array(json.dumps(f_seq)), f_pos_json=np.array(json.dumps(f_pos)),
+        f_neg_json=np.array(json.dumps(f_neg)), feat_types_json=np.array(json.dumps(FEATURE_TYPES_TRAIN)),
+        feat_stats_json=np.array(json.dumps(FEATURE_STATS_TRAIN)), **bt)
+    for i, dr in enumerate(draws):
+        store[f"{prefix}/draw{i}"] = dr.numpy()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            store[f"{prefix}/grad/{k}"] = p.grad.detach().numpy()
+
+
 def main():
     only = set(sys.argv[1:])
     groups = {"g1_pscan": g1_pscan, "g2_selective_scan": g2_selective_scan, "g3_rmsnorm": g3_rmsnorm,
               "g4_mamba": g4_mamba, "g5_mhm": g5_mhm, "g6_blocks": g6_blocks, "g7_multiscale": g7_multiscale,
-              "g9_topk": g9_topk, "g10_train": g10_train, "g11_item_embs": g11_item_embs, "g12_d128": g12_d128}
+              "g9_topk": g9_topk, "g10_train": g10_train, "g11_item_embs": g11_item_embs, "g12_d128": g12_d128,
+              "g13_features": g13_features}
     for fname, fn in groups.items():
         if only and fname not in only:
             continue

@@ -163,7 +163,7 @@ def test_input_assembly_is_fp32_tight():
     ref = O.Hydra(int(s[p + "/U"]), int(s[p + "/I"]), {}, O.IDS_ONLY_FEAT_TYPES, O.make_args(16, int(s[p + "/L"])))
     ref.load_state_dict(G.params(s, p), strict=True)
     b = {k: G.t(s, f"{p}/{k}") for k in ("seq", "tok", "ts", "act", "dwell")}
-    want, pm = ref.assemble_inputs(b["seq"], None, b["tok"], b["ts"], b["act"], b["dwell"])
+    want, pm = ref.assemble_inputs(b["seq"], [[] for _ in range(b["seq"].shape[0])], b["tok"], b["ts"], b["act"], b["dwell"])
     got, pm2 = m.assemble_inputs(*(b[k].to(DEV) for k in ("seq", "tok", "ts", "act", "dwell")))
     assert torch.equal(pm2.cpu(), pm)
     close(got, want, 1e-4, 1e-4, "assembled inputs")

@@ -1,0 +1,188 @@
+"""GPU parity of the feature-fusion paths (embedding.py:216-264, 486-652) through the drop-in SharedEmbeddingModule,
+i.e. through the C ABI, against (1) what the reference itself produced (tests/golden/g13_features.npz) and (2) torch
+fp32 for the row kernels on their own.
+
+Tolerance: row gathers, bag sums, activations, gates and LayerNorm are fp32 (1e-5 class); the projections run on
+split-bf16 MFMA, so module outputs and gradients are asserted at the encoder tolerances of test_gpu_encoder.py
+(max 2e-3 / rms 1e-3 forward, 4x / 6.5x for parameter gradients)."""
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+from generative_recommenders_amd import enc_ops as E
+from generative_recommenders_amd import feature_ops as FO
+from generative_recommenders_amd import hydra as H
+from generative_recommenders_amd import shared_embedding as SE
+from test_gpu_encoder import close
+from test_oracle_golden import feature_module_from, feature_runs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("n,bag,d,rows", [(37, 3, 16, 50), (1000, 5, 64, 4000), (9, 1, 6, 7), (4, 0, 8, 5), (0, 4, 8, 5)])
+def test_bag_sum_forward_backward(n, bag, d, rows):
+    g = torch.Generator().manual_seed(n + bag)
+    w = torch.randn(rows, d, generator=g)
+    ids = torch.randint(0, rows, (n, bag), generator=g)
+    if n and bag:
+        ids[0, 0] = 0
+    G_ = torch.randn(n, d, generator=g)
+    wr = w.clone().requires_grad_()
+    want = torch.nn.functional.embedding(ids, wr, padding_idx=0).sum(1)
+    want.backward(G_)
+    wd = w.to(DEV).requires_grad_()
+    got = FO.gather_sum_rows(wd, ids.to(DEV), 0)
+    got.backward(G_.to(DEV))
+    G.assert_close(got.detach().cpu(), want.detach(), 1e-6, 1e-6, "bag sum")
+    G.assert_close(wd.grad.cpu(), wr.grad, 1e-5, 1e-6, "bag sum table grad")
+    assert float(wd.grad[0].abs().sum()) == 0.0            # padding row
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003])
+def test_activations_and_gate(n):
+    g = torch.Generator().manual_seed(n)
+    x, q, G_ = (torch.randn(n, generator=g) * 2 for _ in range(3))
+    for fn, ref in ((FO.relu, torch.relu), (FO.gelu, torch.nn.functional.gelu)):
+        xr = x.clone().requires_grad_()
+        ref(xr).backward(G_)
+        xd = x.to(DEV).requires_grad_()
+        y = fn(xd)
+        y.backward(G_.to(DEV))
+        G.assert_close(y.detach().cpu(), ref(x), 1e-5, 1e-6, fn.__name__)
+        G.assert_close(xd.grad.cpu(), xr.grad, 1e-4, 1e-6, fn.__name__ + " grad")
+    pr, qr = x.clone().requires_grad_(), q.clone().requires_grad_()
+    (pr * torch.sigmoid(qr)).backward(G_)
+    pd, qd = x.to(DEV).requires_grad_(), q.to(DEV).requires_grad_()
+    y = FO.sigmoid_gate(pd, qd)
+    y.backward(G_.to(DEV))
+    G.assert_close(y.detach().cpu(), x * torch.sigmoid(q), 1e-5, 1e-6, "gate")
+    G.assert_close(pd.grad.cpu(), pr.grad, 1e-4, 1e-6, "gate dp")
+    G.assert_close(qd.grad.cpu(), qr.grad, 1e-4, 1e-6, "gate dq")
+
+
+@pytest.mark.parametrize("T,d", [(1, 16), (37, 32), (1000, 256), (5000, 64), (3, 512), (0, 16)])
+def test_layernorm(T, d):
+    g = torch.Generator().manual_seed(T + d)
+    x = torch.randn(T, d, generator=g) * 3 + 1
+    w, b, G_ = torch.randn(d, generator=g), torch.randn(d, generator=g), torch.randn(T, d, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    torch.nn.functional.layer_norm(xr, (d,), wr, br).backward(G_)
+    xd, wd, bd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = FO.layernorm(xd, wd, bd)
+    y.backward(G_.to(DEV))
+    G.assert_close(y.detach().cpu(), torch.nn.functional.layer_norm(x, (d,), w, b), 1e-4, 1e-5, "layernorm")
+    G.assert_close(xd.grad.cpu(), xr.grad, 1e-3, 2e-5, "layernorm dx")
+    G.assert_close(wd.grad.cpu(), wr.grad, 1e-3, 1e-4 * max(1, T) ** 0.5, "layernorm dw")
+    G.assert_close(bd.grad.cpu(), br.grad, 1e-3, 1e-4 * max(1, T) ** 0.5, "layernorm db")
+
+
+def test_projection_column_blocks_and_unit_width_input():
+    """Column blocks of one wide weight accumulated launch by launch equal the projection of the concatenation, and
+    the Linear(1, d) of a continual feature (K = 1) runs on the same kernel."""
+    g = torch.Generator().manual_seed(5)
+    T, d = 77, 16
+    parts = [torch.randn(T, d, generator=g) for _ in range(3)]
+    W, b, G_ = torch.randn(d, 3 * d, generator=g), torch.randn(d, generator=g), torch.randn(T, d, generator=g)
+    Wr = W.clone().requires_grad_()
+    pr = [p.clone().requires_grad_() for p in parts]
+    torch.nn.functional.linear(torch.cat(pr, 1), Wr, b).backward(G_)
+    Wd = W.to(DEV).requires_grad_()
+    pd = [p.to(DEV).requires_grad_() for p in parts]
+    acc = None
+    for i, p in enumerate(pd):
+        acc = E.linear(p, Wd, b.to(DEV) if i == 0 else None, r1=acc, c1=1.0 if acc is not None else 0.0, col_off=i * d)
+    acc.backward(G_.to(DEV))
+    close(acc, torch.nn.functional.linear(torch.cat(parts, 1), W, b), 2e-3, 1e-3, "blocks")
+    close(Wd.grad, Wr.grad, 8e-3, 6.5e-3, "blocks dW")
+    for a, r in zip(pd, pr):
+        close(a.grad, r.grad, 4e-3, 2.5e-3, "blocks dx")
+    x1, W1, b1 = torch.randn(T, 1, generator=g), torch.randn(d, 1, generator=g), torch.randn(d, generator=g)
+    W1r, b1r = W1.clone().requires_grad_(), b1.clone().requires_grad_()
+    torch.nn.functional.linear(x1, W1r, b1r).backward(G_)
+    W1d, b1d = W1.to(DEV).requires_grad_(), b1.to(DEV).requires_grad_()
+    y = E.linear(x1.to(DEV), W1d, b1d)
+    y.backward(G_.to(DEV))
+    close(y, torch.nn.functional.linear(x1, W1, b1), 2e-3, 1e-3, "K = 1")
+    close(W1d.grad, W1r.grad, 8e-3, 6.5e-3, "K = 1 dW")
+    close(b1d.grad, b1r.grad, 8e-3, 6.5e-3, "K = 1 db")
+
+
+def _module(s, p):
+    se, args = feature_module_from(s, p, SE.SharedEmbeddingModule, device=DEV)
+    return se, args
+
+
+@pytest.mark.parametrize("run", ["early_user", "early_item", "late_item", "late_user", "gated_user"])
+def test_feature_fusion_styles_against_reference_golden(run):
+    s, p = G.load("g13_features"), "G13_mix"
+    se, _ = _module(s, p)
+    se.load_state_dict(G.params(s, p), strict=True)        # every reference key, nothing else
+    se.to(DEV).eval()
+    y = feature_runs(se, s, p, to=lambda x: x.to(DEV))[run]()
+    close(y, G.t(s, f"{p}/{run}/y"), 2e-3, 1e-3, run)
+    y.backward(G.t(s, f"{p}/{run}/G").to(DEV))
+    gold = G.grads(s, f"{p}/{run}")
+    got = {k: q.grad for k, q in se.named_parameters() if q.grad is not None}
+    assert set(gold) == set(got), set(gold) ^ set(got)
+    for k in gold:
+        close(got[k], gold[k], 8e-3, 6.5e-3, f"{run} grad {k}")
+
+
+def test_prepacked_tensor_features_equal_the_list_format():
+    """A dict {feature id: tensor} (ids (B, L), bags (B, L, A), values (B, L), vectors (B, L, dim)) skips the host
+    packing and must give the same bits as the reference's list-of-dicts format."""
+    s, p = G.load("g13_features"), "G13_mix"
+    se, _ = _module(s, p)
+    se.load_state_dict(G.params(s, p), strict=True)
+    se.to(DEV).eval()
+    feats = G.js(s, p + "/feats_json")
+    packed = {}
+    for kind, k in se._groups(include_user=True, interaction=True):
+        if kind == 'item_emb':
+            packed[k] = torch.from_numpy(SE.pack_dense_feature(feats, k, se.ITEM_EMB_FEAT[k]))
+        elif kind == 'array':
+            packed[k] = torch.from_numpy(SE.pack_array_feature(feats, k))
+        else:
+            packed[k] = torch.from_numpy(SE.pack_scalar_feature(feats, k, kind == 'continual'))
+    with torch.no_grad():
+        for style in ("early", "late", "gated"):
+            a = se.get_feature_embeddings(feats, include_user=True, fusion_style=style)
+            b = se.get_feature_embeddings(packed, include_user=True, fusion_style=style)
+            assert torch.equal(a, b), style
+
+
+def test_candidate_table_with_features_against_reference_golden():
+    s, p = G.load("g13_features"), "G13_mix"
+    se, _ = _module(s, p)
+    se.load_state_dict(G.params(s, p), strict=True)
+    se.to(DEV).eval()
+    item_feats = {int(k): v for k, v in G.js(s, p + "/table/item_feats_json").items()}
+    full = se.get_item_embeddings(item_feats, batch_size=16)
+    close(full, G.t(s, p + "/table/full"), 2e-3, 1e-3, "candidate table")
+    assert float(full[0].abs().sum()) == 0.0
+
+
+def test_train_step_with_features_against_reference_golden():
+    """Hydra.forward + backward with sparse / array / continual features on all three feature arguments, on the
+    reference's own draws: loss to 1e-4, every parameter gradient at the encoder tolerances."""
+    s, p = G.load("g13_features"), "G13_train"
+    se, args = _module(s, p)
+    m = H.Hydra(int(s[p + "/U"]), int(s[p + "/I"]), {}, {}, args, se)
+    m.load_state_dict(G.params(s, p), strict=True)
+    m.to(DEV).train()
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    f_seq, f_pos, f_neg = (G.js(s, f"{p}/f_{k}_json") for k in ("seq", "pos", "neg"))
+    hard, inb = G.assemble_train_draws(s, p, G.t(s, p + "/next_tok") == 1)
+    loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, f_seq, f_pos, f_neg, b["ts"], b["act"],
+             b["dwell"], predrawn=(hard.to(DEV), inb.to(DEV)))
+    loss.backward()
+    assert torch.equal(m.last_mined_ids.cpu(), G.t(s, p + "/mined_ids"))
+    ref_loss = float(s[p + "/loss"])
+    assert abs(loss.item() - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
+    gold = G.grads(s, p)
+    got = {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
+    assert set(gold) == set(got), set(gold) ^ set(got)
+    for k in gold:
+        close(got[k], gold[k], 8e-3, 6.5e-3, f"grad {k}")

@@ -195,3 +195,61 @@ def test_candidate_embedding_generation_matches_reference():
     G.assert_close(O.item_embedding_table(w), G.t(s, "G11/full"), 1e-6, 1e-7, "full table")
     G.assert_close(O.late_item_rows(w, G.t(s, "G11/seq")), G.t(s, "G11/late"), 1e-6, 1e-7, "late")
     G.assert_close(O.late_item_rows(w, G.t(s, "G11/item_ids")), G.t(s, "G11/saved/embedding.fbin"), 1e-6, 1e-7, "saved")
+
+
+# ---- feature-fusion paths (embedding.py:216-264, 486-652) ---------------------------------------------------
+def feature_module_from(store, prefix, cls, device='cpu'):
+    U, I, d, L = (int(store[f"{prefix}/{k}"]) for k in "UIdL")
+    args = O.make_args(d, L, dropout=0.0)
+    args.device = device
+    inter = G.js(store, prefix + "/interaction_json") if prefix + "/interaction_json" in store else None
+    se = cls(U, I, G.js(store, prefix + "/feat_stats_json"), G.js(store, prefix + "/feat_types_json"), args, inter)
+    return se, args
+
+
+def feature_runs(se, s, p, to=lambda x: x):
+    feats = G.js(s, p + "/feats_json")
+    seq, tok, pos, poss = (to(G.t(s, f"{p}/{k}")) for k in ("seq", "tok", "pos", "poss"))
+    return {"early_user": lambda: se.get_complete_embeddings(seq, feats, mask=tok, include_user=True, fusion_style="early",
+                                                             model_style="hydra", pos_seq=poss),
+            "early_item": lambda: se.get_complete_embeddings(pos, feats, mask=tok, include_user=False,
+                                                             fusion_style="early", model_style="hydra"),
+            "late_item": lambda: se.get_complete_embeddings(pos, feats, include_user=False, fusion_style="late"),
+            "late_user": lambda: se.get_feature_embeddings(feats, include_user=True, fusion_style="late"),
+            "gated_user": lambda: se.get_feature_embeddings(feats, include_user=True, fusion_style="gated")}
+
+
+@pytest.mark.parametrize("run", ["early_user", "early_item", "late_item", "late_user", "gated_user"])
+def test_feature_fusion_styles(run):
+    s, p = G.load("g13_features"), "G13_mix"
+    se, _ = feature_module_from(s, p, O.SharedEmbeddingModule)
+    se.load_state_dict(G.params(s, p), strict=True)
+    se.eval()
+    y = feature_runs(se, s, p)[run]()
+    y.backward(G.t(s, f"{p}/{run}/G"))
+    G.assert_close(y, G.t(s, f"{p}/{run}/y"), RT, AT, run)
+    gold = G.grads(s, f"{p}/{run}")
+    got = {k: q.grad for k, q in se.named_parameters() if q.grad is not None}
+    assert set(gold) == set(got), set(gold) ^ set(got)
+    for k in gold:
+        G.assert_close(got[k], gold[k], 3e-4, 3e-5, f"{run} grad {k}")
+
+
+def test_train_step_with_features():
+    s, p = G.load("g13_features"), "G13_train"
+    se, args = feature_module_from(s, p, O.SharedEmbeddingModule)
+    m = O.Hydra(int(s[p + "/U"]), int(s[p + "/I"]), {}, {}, args, se)
+    m.load_state_dict(G.params(s, p), strict=True)
+    m.train()
+    b = {k: G.t(s, f"{p}/{k}") for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    f_seq, f_pos, f_neg = (G.js(s, f"{p}/f_{k}_json") for k in ("seq", "pos", "neg"))
+    torch.manual_seed(int(s[p + "/rng_seed"]))
+    loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, f_seq, f_pos, f_neg, b["ts"], b["act"],
+             b["dwell"])
+    loss.backward()
+    G.assert_close(loss, G.t(s, p + "/loss"), 2e-5, 2e-5, "loss")
+    gold = G.grads(s, p)
+    got = {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
+    assert set(gold) == set(got), set(gold) ^ set(got)
+    for k in gold:
+        G.assert_close(got[k], gold[k], 1e-3, 2e-5, "grad " + k)
