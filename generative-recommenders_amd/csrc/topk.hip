@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64 * kRingWaves, 2) void coarse_bf16_ring_kernel(Co
 // top-K does not clear the threshold by the coarse error margin is re-run exactly like any other uncertain one.
 template <int NB, int KS, int M>
 __global__ __launch_bounds__(64, 2) void warm_threshold_kernel(CoarseParams p, int n_sample, int tile_stride_tiles,
-                                                               float* __restrict__ out_thr) {
+                                                               float* __restrict__ out_thr, int n_out, int64_t n_valid) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     const int qtile = blockIdx.x;
     short8 bq[NB][KS];
@@ -644,6 +644,21 @@ __global__ __launch_bounds__(64, 2) void warm_threshold_kernel(CoarseParams p, i
     if (t + 1 < n_sample) {
         load_tile(a1, t + 1);
         score_tile(a1);
+    }
+    if (n_out > 0) {
+        // the n_out largest sampled values of each half of the sampled rows, 2 * n_out per query, for a caller that
+        // combines the samples of several item ranges (rows of padded queries are not written)
+#pragma unroll
+        for (int g = 0; g < NB; ++g) {
+            const int64_t q = (int64_t)qtile * 32 * NB + 32 * g + j;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                float v = top[g][i];
+                if (v > kNegInf) v = v - fabsf(v) * 1e-6f - 1e-30f;
+                if (i < n_out && q < n_valid) out_thr[(q * 2 + h) * n_out + i] = v;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
@@ -709,6 +724,10 @@ struct RescoreParams {
     float* out_scores;
     int32_t* uncertain;         // (n_q) or null
     const int* ring_error;      // non-null: a set flag marks every query of the launch uncertain
+    float* bound_out;           // (n_q) or null.  Non-null: the completeness decision is left to the caller (lists of
+                                // several item ranges are merged first): bound_out[q] = the score below which rows of
+                                // this range may have been dropped (largest lane threshold + coarse error margin, -inf
+                                // when nothing was dropped) and uncertain[q] only reports a failed launch
 };
 
 __device__ __forceinline__ bool ranks_before(float sa, int64_t ia, float sb, int64_t ib) {
@@ -931,8 +950,9 @@ __global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p)
         kth = found ? bs : kNegInf;
         ++r;
     }
-    if (p.uncertain != nullptr && q_ok && t == 0) {
+    if ((p.uncertain != nullptr || p.bound_out != nullptr) && q_ok && t == 0) {
         int flag = 0;
+        float bound = kNegInf;
         if (tmax > kNegInf) {
             float eps = 0.f;
             if (p.max_row_norm != nullptr) {
@@ -941,10 +961,15 @@ __global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p)
                 // |bf16 coarse score - exact score| <= (2^-8 + small) * |q| * max|t|  (two bf16 roundings per product)
                 eps = 0.00398f * sqrtf(n2) * p.max_row_norm[0];
             }
-            flag = !(kth > tmax + eps);
+            bound = tmax + eps;
+            flag = !(kth > bound);
+        }
+        if (p.bound_out != nullptr) {
+            p.bound_out[q] = bound;
+            flag = 0;
         }
         if (p.ring_error != nullptr && *p.ring_error != 0) flag = 1;
-        p.uncertain[q] = flag;
+        if (p.uncertain != nullptr) p.uncertain[q] = flag;
     }
 }
 
@@ -1091,6 +1116,39 @@ struct Plan {
     size_t total() const { return q_bf16_bytes + cand_bytes + 2 * meta_bytes + thr_bytes + 1280; }
 };
 
+// out[q] = k-th largest of the n_slabs * n_values numbers vals[s * slab_stride + q * n_values + v] (-inf when there are
+// fewer than k).  One thread per query keeps the k largest seen so far in a sorted register array (k <= 16).
+__global__ __launch_bounds__(256) void kth_largest_kernel(const float* __restrict__ vals, int n_slabs, int64_t slab_stride,
+                                                          int64_t n_q, int n_values, int k, float* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_q) return;
+    float top[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) top[i] = kNegInf;
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        const float* src = vals + sl * slab_stride + q * n_values;
+        for (int v = 0; v < n_values; ++v) {
+            float m = src[v];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {      // insert into the descending list
+                const float hi = fmaxf(top[i], m);
+                m = fminf(top[i], m);
+                top[i] = hi;
+            }
+        }
+    }
+    float r = kNegInf;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i == k - 1) r = top[i];
+    out[q] = r;
+}
+
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ dst, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
 int dpad_for(int64_t d) {
     int p = 16;
     while (p < d) p *= 2;
@@ -1176,6 +1234,17 @@ void launch_bf16_ks(const CoarseParams& p, int KS, int KP, hipStream_t s) {
     }
 }
 
+// combined-sample multiplier of the threshold exchange (HMX_TOPK_SAMPLE_BOOST; measured on 8 ranges of 500 K rows with
+// the k-th-of-the-union combine: 1 -> 0.6 ms of sampling + 13.3 ms pass, 2 -> 1.1 + 12.6, 4 -> 2.2 + 12.2)
+int64_t sample_boost() {
+    static const int64_t v = [] {
+        const char* e = getenv("HMX_TOPK_SAMPLE_BOOST");
+        const int64_t x = e ? atoll(e) : 1;
+        return x >= 1 && x <= 64 ? x : 1;
+    }();
+    return v;
+}
+
 bool warm_enabled() {
     static const bool on = [] {
         const char* e = getenv("HMX_TOPK_WARM");
@@ -1185,27 +1254,30 @@ bool warm_enabled() {
 }
 
 template <int NB, int KS>
-void launch_warm_m(int M, const CoarseParams& p, int n_qtiles, int n_sample, int stride_tiles, float* out, hipStream_t s) {
+void launch_warm_m(int M, const CoarseParams& p, int n_qtiles, int n_sample, int stride_tiles, float* out, hipStream_t s,
+                   int n_out, int64_t n_valid) {
     if (M <= 5)
-        hipLaunchKernelGGL((warm_threshold_kernel<NB, KS, 5>), dim3(n_qtiles), dim3(64), 0, s, p, n_sample, stride_tiles, out);
+        hipLaunchKernelGGL((warm_threshold_kernel<NB, KS, 5>), dim3(n_qtiles), dim3(64), 0, s, p, n_sample, stride_tiles, out,
+                           n_out, n_valid);
     else
-        hipLaunchKernelGGL((warm_threshold_kernel<NB, KS, 8>), dim3(n_qtiles), dim3(64), 0, s, p, n_sample, stride_tiles, out);
+        hipLaunchKernelGGL((warm_threshold_kernel<NB, KS, 8>), dim3(n_qtiles), dim3(64), 0, s, p, n_sample, stride_tiles, out,
+                           n_out, n_valid);
 }
 template <int NB>
 void launch_warm_ks(int KS, int M, const CoarseParams& p, int n_qtiles, int n_sample, int stride_tiles, float* out,
-                    hipStream_t s) {
+                    hipStream_t s, int n_out, int64_t n_valid) {
     switch (KS) {
-        case 1: launch_warm_m<NB, 1>(M, p, n_qtiles, n_sample, stride_tiles, out, s); break;
-        case 2: launch_warm_m<NB, 2>(M, p, n_qtiles, n_sample, stride_tiles, out, s); break;
-        case 4: launch_warm_m<NB, 4>(M, p, n_qtiles, n_sample, stride_tiles, out, s); break;
-        default: launch_warm_m<NB, 8>(M, p, n_qtiles, n_sample, stride_tiles, out, s); break;
+        case 1: launch_warm_m<NB, 1>(M, p, n_qtiles, n_sample, stride_tiles, out, s, n_out, n_valid); break;
+        case 2: launch_warm_m<NB, 2>(M, p, n_qtiles, n_sample, stride_tiles, out, s, n_out, n_valid); break;
+        case 4: launch_warm_m<NB, 4>(M, p, n_qtiles, n_sample, stride_tiles, out, s, n_out, n_valid); break;
+        default: launch_warm_m<NB, 8>(M, p, n_qtiles, n_sample, stride_tiles, out, s, n_out, n_valid); break;
     }
 }
 void launch_warm(int NB, int KS, int M, const CoarseParams& p, int n_qtiles, int n_sample, int stride_tiles, float* out,
-                 hipStream_t s) {
-    if (NB == 4) launch_warm_ks<4>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s);
-    else if (NB == 2) launch_warm_ks<2>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s);
-    else launch_warm_ks<1>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s);
+                 hipStream_t s, int n_out = 0, int64_t n_valid = 0) {
+    if (NB == 4) launch_warm_ks<4>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s, n_out, n_valid);
+    else if (NB == 2) launch_warm_ks<2>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s, n_out, n_valid);
+    else launch_warm_ks<1>(KS, M, p, n_qtiles, n_sample, stride_tiles, out, s, n_out, n_valid);
 }
 
 void launch_rescore(const RescoreParams& r, hipStream_t s) {
@@ -1279,13 +1351,19 @@ bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, To
 int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, const uint16_t* table_bf16,
              const float* max_row_norm, int64_t n_rows, int64_t d, int64_t k, const int64_t* exclude, int64_t n_excl,
              int64_t id_offset, int64_t* out_ids, float* out_scores, int32_t* uncertain, void* workspace,
-             size_t workspace_bytes, hipStream_t s) {
+             size_t workspace_bytes, hipStream_t s, const float* ext_thr = nullptr, float* bound_out = nullptr,
+             float* sample_out = nullptr, int64_t sample_ranges = 1, int sample_values = 1) {
+    // ext_thr (n_q): start thresholds supplied by the caller (used in place of the sampled ones); bound_out (n_q):
+    // see RescoreParams; sample_out (n_q, sample_values): only the sampled start thresholds are computed and written
+    // (-inf where this launch shape does not sample), no scoring pass runs.  sample_values = 1: the threshold itself;
+    // an even number 2 m: the m largest sampled values of each half of the sampled rows.
     if (n_q == 0) return HMX_OK;
     TopkPlans tp;
     if (!make_plans(n_q, n_rows, d, k, bf16, tp)) return HMX_EINVAL;
     const Plan& pl = tp.full;
-    if (!queries || !table || !out_ids || !out_scores || !workspace) return HMX_EINVAL;
-    if (bf16 && (!table_bf16 || !max_row_norm || !uncertain)) return HMX_EINVAL;
+    if (!queries || !workspace) return HMX_EINVAL;
+    if (sample_out == nullptr && (!table || !out_ids || !out_scores)) return HMX_EINVAL;
+    if (bf16 && (!table_bf16 || (sample_out == nullptr && (!max_row_norm || !uncertain)))) return HMX_EINVAL;
     if (exclude == nullptr) n_excl = 0;
     if (workspace_bytes < tp.total()) return HMX_EWORKSPACE;
     HmxCarver ws(workspace);
@@ -1373,12 +1451,20 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             r.out_ids = out_ids + q0 * k;
             r.out_scores = out_scores + q0 * k;
             r.uncertain = flags;
+            r.bound_out = (bound_out != nullptr && rows == n_rows) ? bound_out + q0 : nullptr;
             r.ring_error = (ring && ring_pass(plan.NB, plan.KS, rows)) ? ring_error : nullptr;
             launch_rescore(r, s);
             HMX_CHECK_LAUNCH();
             return HMX_OK;
         };
         const float* thr0 = nullptr;
+        const bool samples = bf16 && tp.n_seed == 0 && pl.KP == 32 && pl.n_splits == 1 && warm_enabled();
+        if (sample_out != nullptr && !samples) {
+            hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)hmx_ceil_div(nq * sample_values, 256)), dim3(256), 0, s,
+                               sample_out + q0 * sample_values, nq * sample_values, kNegInf);
+            HMX_CHECK_LAUNCH();
+            continue;
+        }
         for (int lvl = 0; lvl < tp.n_seed; ++lvl) {
             // exact top-K of the prefix lands in the output buffers (overwritten by the next pass)
             const int rc = pass(tp.seed[lvl], tp.seed_rows[lvl], thr0, nullptr, "topk_seed_bf16");
@@ -1389,12 +1475,25 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             HMX_CHECK_LAUNCH();
             thr0 = init_thr;
         }
-        if (bf16 && tp.n_seed == 0 && pl.KP == 32 && pl.n_splits == 1 && warm_enabled()) {
+        if (samples && ext_thr != nullptr && sample_out == nullptr) {
+            // start thresholds from the caller (e.g. the largest of the sampled thresholds of all item ranges)
+            if (hipMemsetAsync(init_thr, 0, (size_t)rows_pad * sizeof(float), s) != hipSuccess ||
+                hipMemcpyAsync(init_thr, ext_thr + q0, (size_t)nq * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return HMX_ELAUNCH;
+            thr0 = init_thr;
+        } else if (samples) {
             // many queries, every wave walks the whole table: sampled warm-up thresholds (see warm_threshold_kernel)
             const int64_t full_tiles = n_rows / 32;
             // 1/32 of the tiles, but not fewer than 4096 (short item ranges need relatively more: the start-up work
             // of a pass depends on the absolute number of rows seen), and never more than 1/6 (measured on a 500 K-row range: 1/4 21 ms, 1/6 17 ms, 1/8 18 ms, 1/16 20 ms, 1/32 21 ms)
-            const int n_sample = (int)std::min<int64_t>(std::max<int64_t>(full_tiles / 32, std::min<int64_t>(4096, full_tiles / 6)), 8192);
+            int n_sample = (int)std::min<int64_t>(std::max<int64_t>(full_tiles / 32, std::min<int64_t>(4096, full_tiles / 6)), 8192);
+            if (sample_out != nullptr && sample_ranges > 1) {
+                // this range's sample is one of `sample_ranges` that the caller combines (largest threshold wins):
+                // the combined sample is sized like that of one table of the combined length
+                const int64_t all_tiles = full_tiles * sample_ranges;
+                const int64_t all = std::min<int64_t>(std::max<int64_t>(all_tiles / 32, std::min<int64_t>(4096, all_tiles / 6)), 8192);
+                n_sample = (int)std::min<int64_t>(std::max<int64_t>(hmx_ceil_div(all * sample_boost(), sample_ranges), 64), full_tiles);
+            }
             if (n_sample >= 64) {
                 const int stride_tiles = (int)((full_tiles - 1) / (n_sample - 1));
                 CoarseParams wp{};
@@ -1403,12 +1502,28 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
                 wp.dpad = pl.dpad;
                 wp.debug_skip_publish = -1;
                 void* span = hmx_profile_begin("topk_warm_bf16", s);
-                launch_warm(pl.NB, pl.KS, k <= 10 ? 5 : 8, wp, n_qtiles, n_sample, stride_tiles, init_thr, s);
+                if (sample_out != nullptr && sample_values > 1)
+                    launch_warm(pl.NB, pl.KS, k <= 10 ? 5 : 8, wp, n_qtiles, n_sample, stride_tiles,
+                                sample_out + q0 * sample_values, s, sample_values / 2, nq);
+                else
+                    launch_warm(pl.NB, pl.KS, k <= 10 ? 5 : 8, wp, n_qtiles, n_sample, stride_tiles, init_thr, s);
                 hmx_profile_end(span, s);
                 HMX_CHECK_LAUNCH();
                 thr0 = init_thr;
             }
+            if (sample_out != nullptr) {
+                if (thr0 == nullptr) {
+                    hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)hmx_ceil_div(nq * sample_values, 256)), dim3(256), 0, s,
+                                       sample_out + q0 * sample_values, nq * sample_values, kNegInf);
+                    HMX_CHECK_LAUNCH();
+                } else if (sample_values == 1) {
+                    if (hipMemcpyAsync(sample_out + q0, init_thr, (size_t)nq * sizeof(float), hipMemcpyDeviceToDevice, s) !=
+                        hipSuccess)
+                        return HMX_ELAUNCH;
+                }
+            }
         }
+        if (sample_out != nullptr) continue;
         const int rc = pass(pl, n_rows, thr0, uncertain ? uncertain + q0 : nullptr,
                             bf16 ? "topk_coarse_bf16" : "topk_coarse_f32");
         if (rc != HMX_OK) return rc;
@@ -1455,6 +1570,41 @@ extern "C" int hmx_score_topk_bf16(const float* queries, int64_t n_q, const floa
     HMX_ENTER();
     return run_topk(true, queries, n_q, table, table_bf16, max_row_norm, n_rows, d, k, exclude, n_excl, id_offset,
                     out_ids, out_scores, uncertain, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int hmx_topk_sample_thresholds_bf16(const float* queries, int64_t n_q, const uint16_t* table_bf16,
+                                               int64_t n_rows, int64_t d, int64_t k, int64_t n_ranges,
+                                               int64_t n_values, float* thresholds, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+    HMX_ENTER();
+    if ((!thresholds && n_q > 0) || n_ranges < 1) return HMX_EINVAL;
+    // one value, or the m <= 5 (k <= 10; 8 otherwise) largest sampled values of each half
+    if (n_values != 1 && (n_values < 2 || n_values % 2 || n_values / 2 > (k <= 10 ? 5 : 8))) return HMX_EINVAL;
+    return run_topk(true, queries, n_q, nullptr, table_bf16, nullptr, n_rows, d, k, nullptr, 0, 0, nullptr, nullptr,
+                    nullptr, workspace, workspace_bytes, (hipStream_t)stream, nullptr, nullptr, thresholds, n_ranges,
+                    (int)n_values);
+}
+
+extern "C" int hmx_kth_largest_f32(const float* vals, int64_t n_slabs, int64_t slab_stride, int64_t n_q, int64_t n_values,
+                                   int64_t k, float* out, void* stream) {
+    HMX_ENTER();
+    if (n_q == 0) return HMX_OK;
+    if (!vals || !out || n_slabs <= 0 || n_values <= 0 || k <= 0 || k > 16 || n_q < 0) return HMX_EINVAL;
+    hipLaunchKernelGGL(kth_largest_kernel, dim3((unsigned)hmx_ceil_div(n_q, 256)), dim3(256), 0, (hipStream_t)stream, vals,
+                       (int)n_slabs, slab_stride, n_q, (int)n_values, (int)k, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_score_topk_bf16_seeded(const float* queries, int64_t n_q, const float* table,
+                                          const uint16_t* table_bf16, const float* max_row_norm, int64_t n_rows,
+                                          int64_t d, int64_t k, int64_t id_offset, const float* start_thresholds,
+                                          int64_t* out_ids, float* out_scores, float* bounds, int32_t* failed,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    HMX_ENTER();
+    if (n_q > 0 && (!bounds || !failed)) return HMX_EINVAL;
+    return run_topk(true, queries, n_q, table, table_bf16, max_row_norm, n_rows, d, k, nullptr, 0, id_offset, out_ids,
+                    out_scores, failed, workspace, workspace_bytes, (hipStream_t)stream, start_thresholds, bounds);
 }
 
 extern "C" int hmx_debug_ring_skip_publish(int64_t stage) {

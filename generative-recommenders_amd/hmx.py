@@ -54,6 +54,9 @@ PROTOTYPES = {
     "hmx_score_topk_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
     "hmx_score_topk_f32": (c_int, [P, I64, P, I64, I64, I64, P, I64, I64, P, P, P, c_size_t, P]),
     "hmx_score_topk_bf16": (c_int, [P, I64, P, P, P, I64, I64, I64, P, I64, I64, P, P, P, P, c_size_t, P]),
+    "hmx_topk_sample_thresholds_bf16": (c_int, [P, I64, P, I64, I64, I64, I64, I64, P, P, c_size_t, P]),
+    "hmx_kth_largest_f32": (c_int, [P, I64, I64, I64, I64, I64, P, P]),
+    "hmx_score_topk_bf16_seeded": (c_int, [P, I64, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, c_size_t, P]),
     "hmx_topk_merge": (c_int, [P, P, I64, I64, I64, P, P, P]),
     "hmx_debug_ring_skip_publish": (c_int, [I64]),
     "hmx_attn1q_fwd": (c_int, [P, P, P, I64, I64, I64, I64, P, P, P]),

@@ -343,6 +343,57 @@ def score_topk(queries, prepared, k, exclude=None, id_offset=0, return_stats=Fal
     return ids, sc
 
 
+def sample_thresholds(queries, prepared, k, n_ranges=1, n_values=1):
+    """(n_q,) start thresholds the bf16 pass samples from this table (-inf for launch shapes that do not sample):
+    at least k sampled rows of the table score that much.  Exchanged between item-range shards (retrieval.py);
+    n_ranges = how many ranges' thresholds will be combined (each samples its share).  n_values = 2 m returns
+    (n_q, 2 m): the m largest sampled scores of each half of the sampled rows, for a k-th-of-the-union combine."""
+    _need_cuda(queries)
+    q = _f32c(queries)
+    nq, d = q.shape
+    t = prepared.table
+    thr = torch.empty((nq,) if n_values == 1 else (nq, n_values), dtype=torch.float32, device=q.device)
+    L = hmx.lib()
+    ws = workspace(L.hmx_score_topk_workspace_bytes(nq, t.shape[0], d, k), q.device)
+    hmx.check(L.hmx_topk_sample_thresholds_bf16(hmx.ptr(q), nq, hmx.ptr(prepared.bf16), t.shape[0], d, k, n_ranges,
+                                                n_values, hmx.ptr(thr), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
+              "hmx_topk_sample_thresholds_bf16")
+    return thr
+
+
+def kth_largest(vals, k):
+    """vals (S, n_q, v) -> (n_q,): the k-th largest of the S * v numbers of each query (-inf when fewer than k)."""
+    _need_cuda(vals)
+    v = _f32c(vals)
+    S, nq, nv = v.shape
+    out = torch.empty(nq, dtype=torch.float32, device=v.device)
+    hmx.check(hmx.lib().hmx_kth_largest_f32(hmx.ptr(v), S, nq * nv, nq, nv, k, hmx.ptr(out), hmx.current_stream()),
+              "hmx_kth_largest_f32")
+    return out
+
+
+def score_topk_seeded(queries, prepared, k, start_thresholds, id_offset=0):
+    """The bf16 pass from given start thresholds, completeness left to the caller: -> (ids, scores, bounds, failed).
+    A list may hold fewer than k rows (ids -1, scores -inf); bounds[q] is the score below which rows of this table
+    may have been dropped; failed[q] != 0 marks queries of a launch that gave up.  No host synchronisation."""
+    _need_cuda(queries, start_thresholds)
+    q, thr = _f32c(queries), _f32c(start_thresholds)
+    nq, d = q.shape
+    assert thr.shape == (nq,)
+    t = prepared.table
+    ids = torch.empty(nq, k, dtype=torch.int64, device=q.device)
+    sc = torch.empty(nq, k, dtype=torch.float32, device=q.device)
+    bounds = torch.empty(nq, dtype=torch.float32, device=q.device)
+    failed = torch.empty(nq, dtype=torch.int32, device=q.device)
+    L = hmx.lib()
+    ws = workspace(L.hmx_score_topk_workspace_bytes(nq, t.shape[0], d, k), q.device)
+    hmx.check(L.hmx_score_topk_bf16_seeded(hmx.ptr(q), nq, hmx.ptr(t), hmx.ptr(prepared.bf16),
+                                           hmx.ptr(prepared.max_row_norm), t.shape[0], d, k, id_offset, hmx.ptr(thr),
+                                           hmx.ptr(ids), hmx.ptr(sc), hmx.ptr(bounds), hmx.ptr(failed), hmx.ptr(ws),
+                                           ws.numel(), hmx.current_stream()), "hmx_score_topk_bf16_seeded")
+    return ids, sc, bounds, failed
+
+
 def topk_merge(cand_ids, cand_scores):
     """(S, n_q, k) per-shard lists -> global (n_q, k) with the same order / tie-break."""
     _need_cuda(cand_ids, cand_scores)

@@ -38,12 +38,22 @@ class ShardedRetriever:
     sharding; S < world trades table replication (1.5 GB per copy at 4 M x 64) for longer item ranges per wave,
     which the scoring kernel turns into higher MFMA utilisation (its per-query start-up cost is per range).
 
-    local_topk / merge default to the HIP kernels; they are injectable so that the exchange logic can be
-    exercised without a GPU (CPU tests pass the oracle's functions with the gloo backend).
+    Threshold exchange (S > 1, on by default with the HIP kernels): the scoring pass of a range starts from
+    thresholds sampled on that range, and a short range gives a loose sample (the start-up work of a pass depends on
+    the absolute number of rows seen, so a 500 K-row range paid almost the start-up of the 4 M-row table).  The S
+    ranks that score the same queries therefore exchange their sampled thresholds first (one all_gather of one
+    float per query) and all start from the largest: k sampled rows of ANY range above a value make it a valid
+    start for every range.  A range's own list may then hold fewer than k rows, so completeness is decided after
+    the merge (k-th merged score > every range's drop bound); queries that fail it are re-scored exactly on every
+    range at the end of the search (one host synchronisation per search instead of one per chunk).
+
+    local_topk / merge (and `seeded` = (sample, seeded_topk, exact_topk)) default to the HIP kernels; they are
+    injectable so that the exchange logic can be exercised without a GPU (CPU tests pass oracle functions with the
+    gloo backend).
     """
 
     def __init__(self, table_shard, id_offset=0, group=None, local_topk=None, merge=None, chunk=262144,
-                 item_shards=None):
+                 item_shards=None, exchange_thresholds=True, seeded=None):
         self.id_offset = int(id_offset)
         self.group = group
         self.chunk = int(chunk)
@@ -57,7 +67,10 @@ class ShardedRetriever:
             self.prepared = ops.PreparedTable(table_shard) if table_shard.shape[0] > 0 else None
             local_topk = self._hip_local
             merge = ops.topk_merge
+            if exchange_thresholds and seeded is None:
+                seeded = (self._hip_sample, self._hip_seeded, self._hip_exact)
         self.local_topk, self.merge = local_topk, merge
+        self.seeded = seeded if (seeded is not None and self.S > 1) else None
         self.last_stats = {}
 
     def refresh(self, table_shard=None):
@@ -74,19 +87,66 @@ class ShardedRetriever:
         self.last_stats["uncertain"] = self.last_stats.get("uncertain", 0) + st["uncertain"]
         return ids, sc
 
+    def _nothing(self, n, k, device):
+        return (torch.full((n, k), -1, dtype=torch.int64, device=device),
+                torch.full((n, k), float("-inf"), dtype=torch.float32, device=device))
+
+    def _sample_values(self, k):
+        """Sampled scores per query that a range contributes: 2 m (m per half of its sampled rows) with about 1.5 k
+        values over all ranges, so that the k-th largest of the union is rarely cut short by one range's share."""
+        m = min(5 if k <= 10 else 8, max(2, -(-3 * k // (4 * self.S))))
+        return 2 * m if 2 * m * self.S >= k else 1
+
+    def _hip_sample(self, queries, k):
+        from . import ops
+        if self.prepared is None:
+            nv = self._sample_values(k)
+            return torch.full((queries.shape[0],) if nv == 1 else (queries.shape[0], nv), float("-inf"),
+                              device=queries.device)
+        return ops.sample_thresholds(queries, self.prepared, k, n_ranges=self.S, n_values=self._sample_values(k))
+
+    def _hip_seeded(self, queries, k, thr):
+        from . import ops
+        if self.prepared is None:
+            n = queries.shape[0]
+            return (*self._nothing(n, k, queries.device), torch.full((n,), float("-inf"), device=queries.device),
+                    torch.zeros(n, dtype=torch.int32, device=queries.device))
+        return ops.score_topk_seeded(queries, self.prepared, k, thr, id_offset=self.id_offset)
+
+    def _hip_exact(self, queries, k):
+        from . import ops
+        if self.prepared is None or queries.shape[0] == 0:
+            return self._nothing(queries.shape[0], k, queries.device)
+        return ops.score_topk_exact(queries, self.prepared.table, k, id_offset=self.id_offset)
+
+    class _Done:
+        def wait(self):
+            return True
+
     def _all_gather(self, t):
-        """(n, k) per rank -> (world, n, k); one collective, launched asynchronously."""
+        """(n, k) per rank -> (world, n, k); one collective.  RCCL: launched asynchronously on its own stream, wait()
+        orders the current stream behind it.  gloo (CPU tests, and rehearsals with several ranks on one GPU): run to
+        completion here -- its asynchronous form on GPU tensors works from helper threads that synchronise streams,
+        and with further launches and allocations queued behind it on the main thread that was seen to lock up."""
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        blocking = dist.get_backend(self.group) == "gloo" and t.is_cuda
+        if blocking:
+            torch.cuda.synchronize(t.device)
         try:
-            return out, dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+            w = dist.all_gather_into_tensor(out, t, group=self.group, async_op=not blocking)
         except (RuntimeError, NotImplementedError):      # backend without the flat form
-            parts = list(out.unbind(0))
-            return out, dist.all_gather(parts, t, group=self.group, async_op=True)
+            w = dist.all_gather(list(out.unbind(0)), t, group=self.group, async_op=not blocking)
+        if blocking:
+            torch.cuda.synchronize(t.device)
+            return out, self._Done()
+        return out, w
 
     def search(self, queries, k):
         self.last_stats = {}
         if self.world == 1:
             return self.local_topk(queries, k)
+        if self.seeded is not None:
+            return self._search_exchanged(queries, k)
         n_q = queries.shape[0]
         per_group = -(-n_q // self.G)                       # queries per query group (last group may be short)
         lo = min(self.qgroup * per_group, n_q)
@@ -127,3 +187,88 @@ class ShardedRetriever:
             if n:
                 out_ids[q0:q0 + n] = ids[g * qc:g * qc + n]
                 out_sc[q0:q0 + n] = sc[g * qc:g * qc + n]
+
+    # ---- threshold exchange between the item ranges -----------------------------------------------
+    def _search_exchanged(self, queries, k):
+        sample, seeded_topk, exact_topk = self.seeded
+        n_q, dev = queries.shape[0], queries.device
+        per_group = -(-n_q // self.G)
+        lo = min(self.qgroup * per_group, n_q)
+        mine = queries[lo:min(lo + per_group, n_q)]
+        out_ids = torch.empty(n_q, k, dtype=torch.int64, device=dev)
+        out_sc = torch.empty(n_q, k, dtype=torch.float32, device=dev)
+        flags, pending = [], None
+        for c0 in range(0, per_group, self.chunk):
+            qc = min(self.chunk, per_group - c0)
+            part = mine[c0:c0 + qc]
+            if part.shape[0] < qc:       # short last group: zero queries keep the collectives uniform (results dropped)
+                part = torch.cat([part, torch.zeros(qc - part.shape[0], queries.shape[1], dtype=queries.dtype, device=dev)])
+            g_thr, w = self._all_gather(sample(part, k).contiguous())
+            w.wait()
+            start = self._combine_samples(g_thr, qc, k)
+            ids, sc, bounds, failed = seeded_topk(part, k, start)
+            packed = torch.cat([sc, bounds.unsqueeze(1), failed.to(sc.dtype).unsqueeze(1)], dim=1).contiguous()
+            g_ids, w1 = self._all_gather(ids.contiguous())
+            g_pk, w2 = self._all_gather(packed)
+            if pending is not None:
+                flags.append(self._finish_exchanged(pending, out_ids, out_sc, per_group))
+            pending = ((w1, w2), g_ids, g_pk, c0, qc)
+        if pending is not None:
+            flags.append(self._finish_exchanged(pending, out_ids, out_sc, per_group))
+        redo = torch.cat(flags).nonzero().flatten() if flags else torch.empty(0, dtype=torch.int64, device=dev)
+        # the flags derive from all-gathered data: every rank holds the same list, so the collectives below agree
+        self.last_stats["uncertain"] = int(redo.numel())
+        if redo.numel():
+            qidx = torch.cat([f_idx for f_idx in self._flag_index]).to(dev)[redo]
+            ids, sc = exact_topk(queries[qidx], k)
+            g_ids, w1 = self._all_gather(ids.contiguous())
+            g_sc, w2 = self._all_gather(sc.contiguous())
+            w1.wait()
+            w2.wait()
+            n = qidx.numel()
+            ci = g_ids.view(self.G, self.S, n, k)[self.qgroup].contiguous()
+            cs = g_sc.view(self.G, self.S, n, k)[self.qgroup].contiguous()
+            ids, sc = self.merge(ci, cs)
+            out_ids[qidx], out_sc[qidx] = ids, sc
+        return out_ids, out_sc
+
+    def _combine_samples(self, g_thr, qc, k):
+        """Start thresholds of one chunk from the samples of the S ranges that score it.  One value per range: the
+        largest (k sampled rows of that range beat it).  Several sampled scores per range: the k-th largest of them
+        all (k sampled rows of the table beat it) -- tighter, because the best sampled rows are spread over the
+        ranges."""
+        vals = g_thr.view(self.G, self.S, qc, -1)[self.qgroup]              # (S, qc, values per range)
+        if vals.shape[-1] == 1:
+            return vals[..., 0].amax(0)
+        if vals.is_cuda and k <= 16:
+            from . import ops
+            return ops.kth_largest(vals, k)
+        union = vals.permute(1, 0, 2).reshape(qc, -1)
+        return union.topk(k, dim=1).values[:, k - 1].contiguous()
+
+    def _finish_exchanged(self, pending, out_ids, out_sc, per_group):
+        """Merge one chunk; returns the per-query 'not proven complete' flags of its valid queries (the matching
+        global query numbers are appended to self._flag_index)."""
+        works, g_ids, g_pk, c0, qc = pending
+        for w in works:
+            w.wait()
+        k = g_ids.shape[-1]
+        ci = g_ids.view(self.G, self.S, qc, k).permute(1, 0, 2, 3).reshape(self.S, self.G * qc, k).contiguous()
+        pk = g_pk.view(self.G, self.S, qc, k + 2).permute(1, 0, 2, 3).reshape(self.S, self.G * qc, k + 2)
+        ids, sc = self.merge(ci, pk[..., :k].contiguous())
+        bound = pk[..., k].amax(0)
+        failed = pk[..., k + 1].amax(0) > 0
+        flagged = ~(sc[:, k - 1] > bound) | failed
+        n_q = out_ids.shape[0]
+        if c0 == 0:
+            self._flag_index = []
+        keep = []
+        for g in range(self.G):
+            q0 = g * per_group + c0
+            n = max(0, min(qc, n_q - q0))
+            if n:
+                out_ids[q0:q0 + n] = ids[g * qc:g * qc + n]
+                out_sc[q0:q0 + n] = sc[g * qc:g * qc + n]
+                keep.append(flagged[g * qc:g * qc + n])
+                self._flag_index.append(torch.arange(q0, q0 + n))
+        return torch.cat(keep) if keep else flagged[:0]

@@ -132,6 +132,36 @@ int hmx_score_topk_bf16(const float* queries, int64_t n_q, const float* table, c
                         int64_t n_excl, int64_t id_offset, int64_t* out_ids, float* out_scores,
                         int32_t* uncertain, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Item-range shards that score the same queries can start from one another's sampled thresholds (no counterpart in
+ * the reference, which has no multi-GPU path; the exact form it stands for is still hydra3.py:993 + :1006).
+ * hmx_topk_sample_thresholds_bf16 writes, per query, the start threshold that hmx_score_topk_bf16 would sample from
+ * this range (>= k sampled rows of the range score at least that much; -inf for launch shapes that do not sample);
+ * n_ranges >= 1 is the number of ranges whose thresholds the caller will combine (each then samples its share of
+ * what one table of the combined length would).  n_values = 1: thresholds is (n_q), the threshold itself.
+ * n_values = 2 m (m <= 5 for k <= 10, <= 8 otherwise): thresholds is (n_q, 2 m), the m largest sampled scores of
+ * each half of the sampled rows (distinct rows, descending per half); the k-th largest of the values of ALL ranges
+ * is a tighter valid start than the largest per-range threshold.
+ * The largest such value over the ranges is a valid start for every range, because the merged top-k only needs rows
+ * that beat k rows of ANY range.  hmx_score_topk_bf16_seeded then runs the pass from start_thresholds (n_q) and
+ * leaves the completeness decision to the caller, who sees all ranges: a range's list may hold fewer than k rows
+ * (ids -1, scores -inf), bounds[q] is the score below which rows of this range may have been dropped (-inf: none
+ * were), and the merged result of a query is complete iff its k-th merged score > the largest bounds[q] of the
+ * ranges.  failed[q] != 0 only when the launch itself gave up (shared-stream hand-off); such queries, and those that
+ * fail the test above, are re-run with hmx_score_topk_f32 on every range.  Same workspace size as
+ * hmx_score_topk_bf16; no exclusion lists. */
+int hmx_topk_sample_thresholds_bf16(const float* queries, int64_t n_q, const uint16_t* table_bf16, int64_t n_rows,
+                                    int64_t d, int64_t k, int64_t n_ranges, int64_t n_values, float* thresholds,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+/* out[q] = k-th largest (k <= 16) of the n_slabs * n_values numbers vals[s * slab_stride + q * n_values + v], -inf when
+ * there are fewer than k: the combine step for the sampled scores of several ranges, read as all_gather leaves them
+ * (one slab per range). */
+int hmx_kth_largest_f32(const float* vals, int64_t n_slabs, int64_t slab_stride, int64_t n_q, int64_t n_values, int64_t k,
+                        float* out, void* stream);
+int hmx_score_topk_bf16_seeded(const float* queries, int64_t n_q, const float* table, const uint16_t* table_bf16,
+                               const float* max_row_norm, int64_t n_rows, int64_t d, int64_t k, int64_t id_offset,
+                               const float* start_thresholds, int64_t* out_ids, float* out_scores, float* bounds,
+                               int32_t* failed, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Test hook (no counterpart in the reference).  The shared-stream form of the bf16 coarse pass hands item rows from
  * wave to wave through counters in LDS with bounded waits; a wait that runs out makes the whole workgroup stop
  * early and flags every query of the launch `uncertain`.  This call arms a one-shot fault for the NEXT launch of

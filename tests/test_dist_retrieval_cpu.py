@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, item_shards=None, n_q=70):
+def _worker(rank, world, port, out_dir, item_shards=None, n_q=70, exchange=None):
     from oracle import c_oracle as C
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,8 +38,34 @@ def _worker(rank, world, port, out_dir, item_shards=None, n_q=70):
         ids, sc = C.topk_merge(ci.numpy(), cs.numpy())
         return torch.from_numpy(ids), torch.from_numpy(sc)
 
-    r = ShardedRetriever(None, id_offset=lo, local_topk=local, merge=merge, chunk=32, item_shards=item_shards)
+    # stand-ins for the threshold-exchange kernels: thresholds sampled from every third row of the shard, a pass
+    # that drops every row at or below its start threshold (bound = that threshold), and the exact local scorer
+    def sample(queries, k):
+        sub = shard[::3]
+        if sub.shape[0] < k:
+            return torch.full((queries.shape[0],), float("-inf"))
+        srt = np.sort(queries.numpy() @ sub.T, axis=1)
+        if exchange == "union":          # the three best sampled scores of the range: the k-th of all ranges' is used
+            return torch.from_numpy(srt[:, -3:].copy())
+        thr = torch.from_numpy(srt[:, -k].copy())
+        if exchange == "too_high":       # every seventh query starts above all scores: the re-run must repair it
+            thr[::7] = 1e9
+        return thr
+
+    def seeded_topk(queries, k, thr):
+        ids, sc = local(queries, k)
+        drop = sc <= thr.unsqueeze(1)
+        ids[drop], sc[drop] = -1, float("-inf")
+        return ids, sc, thr.clone(), torch.zeros(queries.shape[0], dtype=torch.int32)
+
+    seeded = (sample, seeded_topk, local) if exchange else None
+    r = ShardedRetriever(None, id_offset=lo, local_topk=local, merge=merge, chunk=32, item_shards=item_shards,
+                         seeded=seeded)
     ids, sc = r.search(q, 10)
+    if exchange == "too_high" and S > 1:
+        assert r.last_stats["uncertain"] >= -(-n_q // 7)
+    elif exchange and S > 1:
+        assert r.last_stats["uncertain"] == 0
     want_ids, want_sc = C.score_topk(q.numpy(), table, 10)
     ok = np.array_equal(ids.numpy(), want_ids) and np.array_equal(sc.numpy(), want_sc)
     with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
@@ -56,6 +82,15 @@ def test_two_rank_sharded_retrieval_equals_unsharded(tmp_path):
 def test_four_rank_grid_equals_unsharded(tmp_path, item_shards, n_q):
     """4 ranks as S item shards x 4/S query groups, incl. a query count the groups do not divide."""
     mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), item_shards, n_q), nprocs=4, join=True)
+    assert [open(tmp_path / f"ok{r}").read() for r in range(4)] == ["1"] * 4
+
+
+@pytest.mark.parametrize("item_shards,n_q,mode", [(2, 70, "plain"), (4, 67, "plain"), (2, 67, "too_high"),
+                                                  (4, 70, "too_high"), (1, 70, "plain"), (4, 70, "union")])
+def test_threshold_exchange_equals_unsharded(tmp_path, item_shards, n_q, mode):
+    """The ranges start from the largest of their sampled thresholds, local lists may be short, completeness is
+    decided after the merge; start values above every score force the exact re-run, which must repair them."""
+    mp.spawn(_worker, args=(4, _free_port(), str(tmp_path), item_shards, n_q, mode), nprocs=4, join=True)
     assert [open(tmp_path / f"ok{r}").read() for r in range(4)] == ["1"] * 4
 
 
