@@ -218,6 +218,117 @@ __global__ __launch_bounds__(kBlock) void layernorm_bwd_kernel(const float* __re
     }
 }
 
+
+// ---- multi-head attention core (nn.MultiheadAttention inside the cross-modal fusion, embedding.py:48-53, :76-78) ----
+// q (B * Lq, d) and kv (B * Lk, 2 d) = [k | v] are the projected inputs, heads are column blocks of hd = d / H.
+// One wave per (sequence, head, query): lanes own keys for the scores and the softmax, then feature columns for
+// the weighted sum (weights parked in LDS).  drop (B, H, Lq, Lk), optional: dropout multiplier of the weights.
+constexpr int kAttnMaxKeys = 4096;
+
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                      const float* __restrict__ drop, int Lq, int Lk, int d, int H,
+                                                      float* __restrict__ p_out, float* __restrict__ out) {
+    __shared__ float w_sh[kAttnMaxKeys];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x % Lq, h = (blockIdx.x / Lq) % H, b = blockIdx.x / (Lq * H);
+    const int hd = d / H;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float* qh = q + ((int64_t)b * Lq + i) * d + h * hd;
+    const float* kvb = kv + (int64_t)b * Lk * 2 * d;
+    const int64_t prow = (((int64_t)b * H + h) * Lq + i) * Lk;
+    float mx = -INFINITY;
+    for (int l = lane; l < Lk; l += 64) {
+        const float* kr = kvb + (int64_t)l * 2 * d + h * hd;
+        float s = 0.f;
+        for (int j = 0; j < hd; ++j) s = __builtin_fmaf(qh[j], kr[j], s);
+        s *= scale;
+        w_sh[l] = s;
+        mx = fmaxf(mx, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+    for (int l = lane; l < Lk; l += 64) {
+        const float e = expf(w_sh[l] - mx);
+        w_sh[l] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int l = lane; l < Lk; l += 64) {
+        const float pr = w_sh[l] * inv;
+        p_out[prow + l] = pr;
+        w_sh[l] = drop ? pr * drop[prow + l] : pr;
+    }
+    __syncthreads();
+    for (int j = lane; j < hd; j += 64) {
+        float acc = 0.f;
+        for (int l = 0; l < Lk; ++l) acc = __builtin_fmaf(w_sh[l], kvb[(int64_t)l * 2 * d + d + h * hd + j], acc);
+        out[((int64_t)b * Lq + i) * d + h * hd + j] = acc;
+    }
+}
+
+// Per query: dw[l] = drop[l] <dout, v_l>, ds[l] = p[l] (dw[l] - sum_l p[l] dw[l]) / sqrt(hd), dq = sum_l ds[l] k_l.
+// ds and the weights that multiplied v (p * drop) go to ds_out / wv_out (B, H, Lq, Lk) for the key-side kernel.
+__global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict__ kv, const float* __restrict__ drop,
+                                                        const float* __restrict__ p_in, const float* __restrict__ dout,
+                                                        int Lq, int Lk, int d, int H, float* __restrict__ dq,
+                                                        float* __restrict__ ds_out, float* __restrict__ wv_out) {
+    __shared__ float ds_sh[kAttnMaxKeys];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x % Lq, h = (blockIdx.x / Lq) % H, b = blockIdx.x / (Lq * H);
+    const int hd = d / H;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float* doh = dout + ((int64_t)b * Lq + i) * d + h * hd;
+    const float* kvb = kv + (int64_t)b * Lk * 2 * d;
+    const int64_t prow = (((int64_t)b * H + h) * Lq + i) * Lk;
+    float dot = 0.f;
+    for (int l = lane; l < Lk; l += 64) {
+        const float* vr = kvb + (int64_t)l * 2 * d + d + h * hd;
+        float dw = 0.f;
+        for (int j = 0; j < hd; ++j) dw = __builtin_fmaf(doh[j], vr[j], dw);
+        const float m = drop ? drop[prow + l] : 1.0f;
+        const float pr = p_in[prow + l];
+        dw *= m;
+        ds_sh[l] = dw;
+        wv_out[prow + l] = pr * m;
+        dot += pr * dw;
+    }
+    dot = wave_sum(dot);
+    for (int l = lane; l < Lk; l += 64) {
+        const float v = p_in[prow + l] * (ds_sh[l] - dot) * scale;
+        ds_sh[l] = v;
+        ds_out[prow + l] = v;
+    }
+    __syncthreads();
+    for (int j = lane; j < hd; j += 64) {
+        float acc = 0.f;
+        for (int l = 0; l < Lk; ++l) acc = __builtin_fmaf(ds_sh[l], kvb[(int64_t)l * 2 * d + h * hd + j], acc);
+        dq[((int64_t)b * Lq + i) * d + h * hd + j] = acc;
+    }
+}
+
+// Per key: dk_l = sum_i ds[i, l] q_i, dv_l = sum_i wv[i, l] dout_i, queries added in order (one wave per
+// (sequence, head, key), lanes own feature columns).
+__global__ __launch_bounds__(64) void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ dout,
+                                                         const float* __restrict__ ds, const float* __restrict__ wv,
+                                                         int Lq, int Lk, int d, int H, float* __restrict__ dkv) {
+    const int lane = threadIdx.x;
+    const int l = blockIdx.x % Lk, h = (blockIdx.x / Lk) % H, b = blockIdx.x / (Lk * H);
+    const int hd = d / H;
+    const int64_t pbase = ((int64_t)b * H + h) * Lq * Lk + l;
+    for (int j = lane; j < hd; j += 64) {
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < Lq; ++i) {
+            const int64_t row = ((int64_t)b * Lq + i) * d + h * hd + j;
+            ak = __builtin_fmaf(ds[pbase + (int64_t)i * Lk], q[row], ak);
+            av = __builtin_fmaf(wv[pbase + (int64_t)i * Lk], dout[row], av);
+        }
+        const int64_t o = ((int64_t)b * Lk + l) * 2 * d + h * hd + j;
+        dkv[o] = ak;
+        dkv[o + d] = av;
+    }
+}
+
 int ln_blocks(int64_t T) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(T, kBlock / 64), 512)); }
 
 int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(n, kBlock), kMaxGrid)); }
@@ -321,6 +432,38 @@ extern "C" int hmx_layernorm_bwd(const float* x, const float* weight, const floa
     if (T > 0 && (!x || !weight || !mean || !rstd || !dy || !dx)) return HMX_EINVAL;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ln_blocks(T)), dim3(kBlock), 0, (hipStream_t)stream, x, weight, mean,
                        rstd, dy, T, (int)d, dx, part);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+static bool attn_shape_ok(int64_t B, int64_t Lq, int64_t Lk, int64_t d, int64_t H) {
+    return B >= 0 && Lq > 0 && Lk > 0 && Lk <= kAttnMaxKeys && d > 0 && H > 0 && d % H == 0 &&
+           B * H * std::max(Lq, Lk) < ((int64_t)1 << 31);
+}
+
+extern "C" int hmx_attn_fwd(const float* q, const float* kv, const float* drop, int64_t B, int64_t Lq, int64_t Lk,
+                            int64_t d, int64_t H, float* p, float* out, void* stream) {
+    HMX_ENTER();
+    if (!attn_shape_ok(B, Lq, Lk, d, H)) return HMX_EINVAL;
+    if (B == 0) return HMX_OK;
+    if (!q || !kv || !p || !out) return HMX_EINVAL;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * H * Lq)), dim3(64), 0, (hipStream_t)stream, q, kv, drop, (int)Lq,
+                       (int)Lk, (int)d, (int)H, p, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_attn_bwd(const float* q, const float* kv, const float* drop, const float* p, const float* dout,
+                            int64_t B, int64_t Lq, int64_t Lk, int64_t d, int64_t H, float* dq, float* dkv, float* ds,
+                            float* wv, void* stream) {
+    HMX_ENTER();
+    if (!attn_shape_ok(B, Lq, Lk, d, H)) return HMX_EINVAL;
+    if (B == 0) return HMX_OK;
+    if (!q || !kv || !p || !dout || !dq || !dkv || !ds || !wv) return HMX_EINVAL;
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)(B * H * Lq)), dim3(64), 0, (hipStream_t)stream, kv, drop, p, dout,
+                       (int)Lq, (int)Lk, (int)d, (int)H, dq, ds, wv);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)(B * H * Lk)), dim3(64), 0, (hipStream_t)stream, q, dout, ds, wv,
+                       (int)Lq, (int)Lk, (int)d, (int)H, dkv);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }

@@ -134,6 +134,40 @@ def layernorm(x, weight, bias, eps=1e-5):
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, kv, drop, B, Lq, Lk, H):
+        _need_cuda(q, kv, drop)
+        q, kv = _f32c(q), _f32c(kv)
+        drop = _f32c(drop) if drop is not None else None
+        d = q.shape[1]
+        assert q.shape[0] == B * Lq and kv.shape == (B * Lk, 2 * d) and (drop is None or drop.numel() == B * H * Lq * Lk)
+        p, out = _empty(B, H, Lq, Lk, like=q), _empty(B * Lq, d, like=q)
+        hmx.check(_L().hmx_attn_fwd(hmx.ptr(q), hmx.ptr(kv), hmx.ptr(drop), B, Lq, Lk, d, H, hmx.ptr(p), hmx.ptr(out),
+                                    _s()), "hmx_attn_fwd")
+        ctx.save_for_backward(q, kv, drop, p)
+        ctx.dims = (B, Lq, Lk, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, drop, p = ctx.saved_tensors
+        B, Lq, Lk, H = ctx.dims
+        dout = _f32c(dout)
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ds, wv = torch.empty_like(p), torch.empty_like(p)
+        hmx.check(_L().hmx_attn_bwd(hmx.ptr(q), hmx.ptr(kv), hmx.ptr(drop), hmx.ptr(p), hmx.ptr(dout), B, Lq, Lk,
+                                    q.shape[1], H, hmx.ptr(dq), hmx.ptr(dkv), hmx.ptr(ds), hmx.ptr(wv), _s()),
+                  "hmx_attn_bwd")
+        return dq, dkv, None, None, None, None, None
+
+
+def attention(q, kv, drop, B, Lq, Lk, H):
+    """Multi-head attention core on projected rows: q (B * Lq, d), kv (B * Lk, 2 d) = [k | v] -> (B * Lq, d);
+    drop (B, H, Lq, Lk) or None multiplies the softmax weights."""
+    return _Attention.apply(q, kv, drop, B, Lq, Lk, H)
+
+
 def linear_any(x2, weight, bias=None, r1=None, col_off=0, cols=None):
     """nn.Linear on a (T, K) input through hmx_linear_f32 (K <= 256); a wider input (the raw multimodal item
     embeddings, 1024 to 4096 columns) is a plain library GEMM and goes to torch's (hipBLASLt)."""

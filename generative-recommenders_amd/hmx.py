@@ -115,6 +115,8 @@ PROTOTYPES = {
     "hmx_layernorm_bwd_blocks": (I64, [I64]),
     "hmx_layernorm_fwd": (c_int, [P, P, P, I64, I64, F, P, P, P, P]),
     "hmx_layernorm_bwd": (c_int, [P, P, P, P, P, I64, I64, P, P, P]),
+    "hmx_attn_fwd": (c_int, [P, P, P, I64, I64, I64, I64, I64, P, P, P]),
+    "hmx_attn_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, P]),
     "hmx_profile_enable": (c_int, [c_int]),
     "hmx_profile_collect": (c_int, [c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }

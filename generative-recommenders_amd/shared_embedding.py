@@ -6,9 +6,8 @@ follow embedding.py:12-214, 429-454, 486-652 so that reference checkpoints load 
 unchanged.  Id tables: HIP gather / deterministic scatter-add.  Feature groups (sparse, array, continual,
 interaction, multimodal item embeddings) in the three fusion styles: HIP row gathers, bag sums, projections,
 activations, gates and LayerNorm; the projections of one concatenated input are column blocks of the wide weight
-accumulated in place, so no concatenated tensor is built.  The attention core of the cross-modal fusion (softmax of
-an L x L score matrix per modality pair) and the raw multimodal inputs' first projection (K of 1024 to 4096: a plain
-library GEMM) are torch GPU ops.
+accumulated in place, so no concatenated tensor is built.  Torch GPU ops that remain: the raw multimodal inputs'
+first projection (K of 1024 to 4096: a plain library GEMM), their L2 normalisation, and the dropout draws.
 """
 import numpy as np
 import torch
@@ -97,6 +96,15 @@ class ModalitySpecificEncoder(nn.Module):
         return y.view(*x.shape[:-1], y.shape[-1])
 
 
+def _weighted_sum(tensors, coef=1.0):
+    """coef * sum(tensors) over (T, d) rows on the HIP combine kernel (four operands per launch)."""
+    acc = E.combine_ad(tensors[:4], [coef] * len(tensors[:4]))
+    for i in range(4, len(tensors), 3):
+        more = tensors[i:i + 3]
+        acc = E.combine_ad([acc] + more, [1.0] + [coef] * len(more))
+    return acc
+
+
 class CrossModalFusionLayer(nn.Module):
     """embedding.py:12-89: every modality attends to every other one, the mean of what it receives is added through
     a learned gate, the enhanced modalities are summed and LayerNorm-ed."""
@@ -120,12 +128,10 @@ class CrossModalFusionLayer(nn.Module):
         d, H = self.hidden_dim, self.num_heads
         q = E.linear(src2, mha.in_proj_weight[:d], mha.in_proj_bias[:d])
         kv = E.linear(tgt2, mha.in_proj_weight[d:], mha.in_proj_bias[d:])
-        qh = q.view(B, L, H, d // H).transpose(1, 2)
-        kh = kv[:, :d].reshape(B, L, H, d // H).transpose(1, 2)
-        vh = kv[:, d:].reshape(B, L, H, d // H).transpose(1, 2)
-        w = torch.softmax(qh @ kh.transpose(-1, -2) * (d // H) ** -0.5, dim=-1)
-        w = torch.nn.functional.dropout(w, mha.dropout, self.training)
-        ctxv = (w @ vh).transpose(1, 2).reshape(B * L, d)
+        drop = None
+        if self.training and mha.dropout > 0:      # the multiplier nn.MultiheadAttention applies to its weights
+            drop = torch.nn.functional.dropout(torch.ones(B, H, L, L, device=q.device), mha.dropout, True)
+        ctxv = FO.attention(q, kv, drop, B, L, L, H)
         return E.linear(ctxv, mha.out_proj.weight, mha.out_proj.bias)
 
     def forward(self, modality_features):
@@ -134,21 +140,17 @@ class CrossModalFusionLayer(nn.Module):
         B, L, d = modality_features[0].shape
         rows = [m.reshape(B * L, d) for m in modality_features]
         n = len(rows)
-        fused = None
+        terms = []
         for i, src in enumerate(rows):
-            infl = None
-            for j, tgt in enumerate(rows):
-                if i == j:
-                    continue
-                a = self._attend(self.cross_attentions[f"{i}_{j}"], src, tgt, B, L)
-                infl = a if infl is None else infl + a
-            infl = infl / (n - 1)                                     # torch.stack(...).mean(0)
+            got = [self._attend(self.cross_attentions[f"{i}_{j}"], src, tgt, B, L)
+                   for j, tgt in enumerate(rows) if j != i]
+            infl = _weighted_sum(got, 1.0 / (n - 1))                  # torch.stack(...).mean(0)
             glin = self.fusion_gates[i][0]
             # gate = sigmoid(W [src | infl] + b): the two halves of the weight applied to the two inputs
             q = E.linear(src, glin.weight, glin.bias)
             q = E.linear(infl, glin.weight, None, r1=q, c1=1.0, col_off=d)
-            enhanced = src + FO.sigmoid_gate(infl, q)
-            fused = enhanced if fused is None else fused + enhanced
+            terms += [src, FO.sigmoid_gate(infl, q)]                  # enhanced_i = src + gate * influence
+        fused = _weighted_sum(terms)
         return FO.layernorm(fused, self.norm.weight, self.norm.bias, self.norm.eps).view(B, L, d)
 
 

@@ -474,6 +474,18 @@ int hmx_layernorm_fwd(const float* x, const float* weight, const float* bias, in
 int hmx_layernorm_bwd(const float* x, const float* weight, const float* mean, const float* rstd, const float* dy,
                       int64_t T, int64_t d, float* dx, float* part, void* stream);
 
+/* Attention core of nn.MultiheadAttention(batch_first=True) as the cross-modal fusion uses it (embedding.py:48-53,
+ * :76-78: query = one modality's sequence, key = value = another's; no masks).  q (B * Lq, d) and kv (B * Lk, 2 d) =
+ * [k | v] are the ALREADY PROJECTED inputs (in_proj through hmx_linear_f32), heads are column blocks of d / H:
+ *   out[b, i, h-block] = sum_l softmax_l(<q_i, k_l> / sqrt(d / H)) * drop[b, h, i, l] * v_l.
+ * drop (B, H, Lq, Lk) is the dropout multiplier of the attention weights (NULL in eval).  p (B, H, Lq, Lk) receives
+ * the softmax weights for the backward pass, which writes dq (B * Lq, d), dkv (B * Lk, 2 d) and uses ds, wv
+ * (B, H, Lq, Lk each) as scratch.  Lk <= 4096. */
+int hmx_attn_fwd(const float* q, const float* kv, const float* drop, int64_t B, int64_t Lq, int64_t Lk, int64_t d,
+                 int64_t H, float* p, float* out, void* stream);
+int hmx_attn_bwd(const float* q, const float* kv, const float* drop, const float* p, const float* dout, int64_t B,
+                 int64_t Lq, int64_t Lk, int64_t d, int64_t H, float* dq, float* dkv, float* ds, float* wv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,35 @@ def test_layernorm(T, d):
     G.assert_close(bd.grad.cpu(), br.grad, 1e-3, 1e-4 * max(1, T) ** 0.5, "layernorm db")
 
 
+@pytest.mark.parametrize("B,Lq,Lk,d,H,with_drop", [(2, 5, 5, 16, 2, False), (3, 100, 100, 64, 2, True),
+                                                  (1, 7, 130, 32, 4, True), (2, 1, 3, 8, 1, False)])
+def test_attention_core(B, Lq, Lk, d, H, with_drop):
+    """softmax(q k^T / sqrt(hd)) (times a dropout multiplier) v per head, against the same formula in torch."""
+    g = torch.Generator().manual_seed(B * 100 + Lq)
+    q, kv, G_ = torch.randn(B * Lq, d, generator=g), torch.randn(B * Lk, 2 * d, generator=g), torch.randn(B * Lq, d, generator=g)
+    drop = ((torch.rand(B, H, Lq, Lk, generator=g) > 0.3).float() / 0.7) if with_drop else None
+    hd = d // H
+
+    def ref(q, kv):
+        qh = q.view(B, Lq, H, hd).transpose(1, 2)
+        kh = kv[:, :d].reshape(B, Lk, H, hd).transpose(1, 2)
+        vh = kv[:, d:].reshape(B, Lk, H, hd).transpose(1, 2)
+        w = torch.softmax(qh @ kh.transpose(-1, -2) * hd ** -0.5, dim=-1)
+        if drop is not None:
+            w = w * drop
+        return (w @ vh).transpose(1, 2).reshape(B * Lq, d)
+
+    qr, kvr = q.clone().requires_grad_(), kv.clone().requires_grad_()
+    want = ref(qr, kvr)
+    want.backward(G_)
+    qd, kvd = q.to(DEV).requires_grad_(), kv.to(DEV).requires_grad_()
+    got = FO.attention(qd, kvd, None if drop is None else drop.to(DEV), B, Lq, Lk, H)
+    got.backward(G_.to(DEV))
+    G.assert_close(got.detach().cpu(), want.detach(), 1e-4, 1e-5, "attention")
+    G.assert_close(qd.grad.cpu(), qr.grad, 1e-3, 2e-5, "attention dq")
+    G.assert_close(kvd.grad.cpu(), kvr.grad, 1e-3, 2e-5, "attention dkv")
+
+
 def test_projection_column_blocks_and_unit_width_input():
     """Column blocks of one wide weight accumulated launch by launch equal the projection of the concatenation, and
     the Linear(1, d) of a continual feature (K = 1) runs on the same kernel."""
