@@ -314,6 +314,8 @@ class SharedEmbeddingModule(nn.Module):
 
     @staticmethod
     def _is_empty(feature_array):
+        if feature_array is None:
+            return True
         if isinstance(feature_array, dict):
             return len(feature_array) == 0
         return len(feature_array) == 0 or len(feature_array[0]) == 0
