@@ -203,7 +203,45 @@ def run_train(args, world, rank, with_cpu_baseline=True):
             traffic = json.load(f).get("hbm_bytes_per_launch")
     gather_gbs = probe_bytes * p_n / (p_ms * 1e-3) / 1e9 if p_ms > 0 else 0.0
     gather_bf16_gbs = probe_bytes_bf16 * b_n / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0
-    del pid
+
+    # The same probes on skewed ids: Zipf(1.05) over the item ranks (continuous inverse-CDF draw), ranks spread over
+    # the table by a fixed multiplicative hash so that popular rows are not neighbours.  Repeated rows come from
+    # cache in the gather and collapse into long runs in the scatter-add, which is what the run sums' dedup is for.
+    gz = torch.Generator(device=dev).manual_seed(6)
+    u = torch.rand(n_probe, device=dev, generator=gz, dtype=torch.float64)
+    s_exp, n_items = 1.05, float(args.items)
+    ranks = ((n_items ** (1.0 - s_exp) - 1.0) * u + 1.0) ** (1.0 / (1.0 - s_exp))
+    zid = (ranks.long().clamp_(1, args.items) * 2654435761 % args.items + 1)
+    del u, ranks
+    ops.gather_rows(table, zid)
+    hmx.profile_enable(True)
+    hmx.profile_collect("gather_rows")
+    for _ in range(5):
+        ops.gather_rows(table, zid)
+    torch.cuda.synchronize()
+    z_ms, z_n = hmx.profile_collect("gather_rows")
+    hmx.profile_enable(False)
+    gather_zipf_gbs = probe_bytes * z_n / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
+
+    # Scatter-add of n_probe gradient rows into a dense (items + 1, d) gradient: whole operation (sort + run sums +
+    # joins), event-timed on the launch stream.  Algorithmic bytes: n (8 + 4 d) + 2 u 4 d, u = distinct rows.
+    scatter = {}
+    grows = torch.randn(n_probe, d, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    dense = torch.zeros(args.items + 1, d, device=dev)
+    for name, idv in (("uniform ids", pid), ("Zipf(1.05) ids", zid)):
+        uniq = int(torch.unique(idv).numel())
+        ops.scatter_add_rows(grows, idv, args.items + 1, 0, out=dense)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ops.scatter_add_rows(grows, idv, args.items + 1, 0, out=dense)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        nbytes = n_probe * (8 + 4 * d) + 2 * uniq * 4 * d
+        scatter[name] = {"ms_per_call": ms, "distinct_rows": uniq, "algorithmic_bytes": nbytes,
+                         "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_8000": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del pid, zid, grows, dense
     out = {
         "metric": "user seqs/s hydra3 fwd+bwd", "value": B * world / step_s, "unit": "user seqs/s",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": step_s * 1e3,
@@ -255,6 +293,10 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                 "achieved_GBps_at_the_fp32_accounting": probe_bytes * b_n / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0,
                 "avg_launch_ms": b_ms / max(b_n, 1), "bytes_moved_per_launch": probe_bytes_bf16,
                 "note": "same ids; the output row is bf16, so a launch moves 392 B per id at d = 64 instead of 520"},
+            "gather_rows_kernel probe, Zipf(1.05) ids (hbm + cache)": {
+                "achieved_GBps_at_520_B_per_id": gather_zipf_gbs, "avg_launch_ms": z_ms / max(z_n, 1),
+                "note": "same launch with skewed ids: repeated rows are served by L2 / Infinity Cache"},
+            f"scatter_add_rows probe, {n_probe} rows of d {d} into the dense item gradient (sort + run sums, hbm)": scatter,
             "gather_rows_kernel inside the step": {"ids_per_step": n_ids, "launches": g_n,
                                                    "ms_per_step": g_ms / args.steps},
             "coarse scoring kernels (miner, mfma)": {"achieved_tflops": miner_tf, "frac_of_2500": miner_tf / 2500.0,

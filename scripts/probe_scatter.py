@@ -1,4 +1,5 @@
-"""Scatter-add probe: n uniform random ids over a rows x d table (defaults: the benchmark's 16.8 M ids, 4 M x 64)."""
+"""Scatter-add probe: n random ids over a rows x d table (defaults: 16.8 M ids, 4 M x 64); a sixth argument "zipf"
+draws the ids Zipf(1.05) over the item ranks (ranks spread over the table by a multiplicative hash)."""
 import sys
 import time
 
@@ -15,6 +16,11 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(3)
 ids = torch.randint(1, rows, (n,), device=dev, generator=g)
+if len(sys.argv) > 5 and sys.argv[5] == "zipf":
+    u = torch.rand(n, device=dev, generator=g, dtype=torch.float64)
+    ranks = ((float(rows - 1) ** -0.05 - 1.0) * u + 1.0) ** (1.0 / -0.05)
+    ids = ranks.long().clamp_(1, rows - 1) * 2654435761 % (rows - 1) + 1
+    del u, ranks
 grad = torch.randn(n, d, device=dev, generator=g)
 out = torch.zeros(rows, d, device=dev)
 ops.scatter_add_rows(grad, ids, rows, 0, out=out)

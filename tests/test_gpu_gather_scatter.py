@@ -70,10 +70,14 @@ def test_scatter_add_bit_exact(rows, d, n, hot):
     assert not got[0].any()
 
 
-@pytest.mark.parametrize("n,distinct,d", [(200_000, 5, 64), (70_000, 1, 64), (5000, 3, 16), (1537, 2, 128), (513, 1, 64)])
+@pytest.mark.parametrize("n,distinct,d", [(200_000, 5, 64), (70_000, 1, 64), (5000, 3, 16), (1537, 2, 128), (513, 1, 64),
+                                          (100_000, 2, 16), (60_000, 3, 128), (50_000, 1, 32), (40_000, 2, 256),
+                                          (20_000, 1, 60), (4608 + 513, 1, 64), (4608 + 511, 1, 64), (300_000, 40, 64)])
 def test_scatter_add_extreme_skew_bit_exact(n, distinct, d):
     """Runs of tens of thousands of equal ids (every user mining the same hard negatives): pieces of 512 entries
-    are summed in parallel and joined in order; the oracle follows the same association."""
+    are summed in parallel and joined in order (runs of more than eight further pieces by a whole wave, through LDS;
+    shorter ones by one lane group; widths that are not a multiple of four always by one group); the oracle follows
+    the same association."""
     g = torch.Generator().manual_seed(n)
     ids = torch.randint(1, distinct + 1, (n,), generator=g) * 7
     grad = torch.randn(n, d, generator=g)
