@@ -6,7 +6,8 @@ Workloads (synthetic data, shapes from BASELINE.json):
   retrieval  top-10 over a 4,000,001 x 64 item table for 1,000,000 user embeddings per step.
              N > 1: the table is cut into S contiguous item-id ranges (--item-shards; default S = N, one range
              per GPU, BASELINE.json configs[3]); every rank scores the queries against its range, the per-range
-             lists are exchanged by RCCL all_gather and merged (strong scaling: the work per step is fixed).
+             lists are exchanged by RCCL all_gather and merged (strong scaling: the work per step is fixed); the
+             ranges start from thresholds sampled on all of them (one more small all_gather per query chunk).
              S < N (opt-in) lets the N / S ranks that hold a copy of a range split the queries.
 Started as `python bench.py --gpus N` without a launcher, the script starts the N ranks itself (torch.distributed.run
 on 127.0.0.1) before it touches the GPU; under torchrun it is one of the ranks.
@@ -44,6 +45,8 @@ def parse():
     ap.add_argument("--item-shards", type=int, default=0,
                     help="item-id ranges the table is cut into (0: N, one range per GPU); N / shards ranks "
                          "hold each range and split the queries")
+    ap.add_argument("--no-threshold-exchange", action="store_true",
+                    help="N > 1: every item range proves its own top-k (no exchange of sampled thresholds between ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-adamw", dest="torch_adamw", action="store_true",
                     help="train workload: torch's clip_grad_norm_ + fused AdamW instead of the HIP optimizer kernels")
@@ -142,7 +145,7 @@ def run_retrieval(args, world, rank):
     del full
     torch.cuda.empty_cache()
     q = synth.queries(args.queries, d, dev)
-    retr = ShardedRetriever(shard, id_offset=lo, item_shards=S)
+    retr = ShardedRetriever(shard, id_offset=lo, item_shards=S, exchange_thresholds=not args.no_threshold_exchange)
     for _ in range(args.warmup):
         retr.search(q, k)
     hmx.profile_enable(True)
@@ -176,7 +179,7 @@ def run_retrieval(args, world, rank):
                                     f"{S} item-range shards x {G} query groups") +
                                    f", {os.environ.get('HMX_BENCH_BACKEND', 'nccl')} all_gather + merge"
                                    if world > 1 else "single GPU"),
-                   "item_shards": S, "query_groups": G},
+                   "item_shards": S, "query_groups": G, "threshold_exchange": retr.seeded is not None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per full 262144-query launch (FETCH_SIZE x 2 + WRITE_SIZE)",
