@@ -1487,6 +1487,10 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             // 1/32 of the tiles, but not fewer than 4096 (short item ranges need relatively more: the start-up work
             // of a pass depends on the absolute number of rows seen), and never more than 1/6 (measured on a 500 K-row range: 1/4 21 ms, 1/6 17 ms, 1/8 18 ms, 1/16 20 ms, 1/32 21 ms)
             int n_sample = (int)std::min<int64_t>(std::max<int64_t>(full_tiles / 32, std::min<int64_t>(4096, full_tiles / 6)), 8192);
+            if (const char* e = getenv("HMX_TOPK_WARM_TILES")) {     // diagnostic override of the sample size
+                const int64_t v = atoll(e);
+                if (v >= 64 && v <= full_tiles) n_sample = (int)v;
+            }
             if (sample_out != nullptr && sample_ranges > 1) {
                 // this range's sample is one of `sample_ranges` that the caller combines (largest threshold wins):
                 // the combined sample is sized like that of one table of the combined length
