@@ -117,6 +117,27 @@ __global__ __launch_bounds__(kBlock) void gate_bwd_kernel(const float* __restric
     }
 }
 
+// out = sigmoid(z) * a + (1 - sigmoid(z)) * l   (the gated mix of the multi-scale fusion tail, hydra3.py:536-541)
+__global__ __launch_bounds__(kBlock) void gate_mix_fwd_kernel(const float* __restrict__ z, const float* __restrict__ a,
+                                                              const float* __restrict__ l, int64_t n,
+                                                              float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float s = sigmoid1(z[i]);
+        out[i] = s * a[i] + (1.0f - s) * l[i];
+    }
+}
+__global__ __launch_bounds__(kBlock) void gate_mix_bwd_kernel(const float* __restrict__ z, const float* __restrict__ a,
+                                                              const float* __restrict__ l, const float* __restrict__ g,
+                                                              int64_t n, float* __restrict__ dz, float* __restrict__ da,
+                                                              float* __restrict__ dl) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float s = sigmoid1(z[i]);
+        dz[i] = g[i] * (a[i] - l[i]) * s * (1.0f - s);
+        da[i] = g[i] * s;
+        dl[i] = g[i] * (1.0f - s);
+    }
+}
+
 // ---- LayerNorm (nn.LayerNorm over the last dimension, biased variance, eps inside the root) -----------
 constexpr int kLnMaxCols = 512;               // columns per row
 constexpr int kLnPerLane = kLnMaxCols / 64;   // columns a lane owns: c = lane + 64 j
@@ -405,6 +426,27 @@ extern "C" int hmx_gate_bwd(const float* p, const float* q, const float* g, int6
     if (n == 0) return HMX_OK;
     if (!p || !q || !g || !dp || !dq) return HMX_EINVAL;
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, p, q, g, n, dp, dq);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_gate_mix_fwd(const float* z, const float* a, const float* l, int64_t n, float* out, void* stream) {
+    HMX_ENTER();
+    if (n < 0) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!z || !a || !l || !out) return HMX_EINVAL;
+    hipLaunchKernelGGL(gate_mix_fwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, z, a, l, n, out);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_gate_mix_bwd(const float* z, const float* a, const float* l, const float* g, int64_t n, float* dz,
+                                float* da, float* dl, void* stream) {
+    HMX_ENTER();
+    if (n < 0) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!z || !a || !l || !g || !dz || !da || !dl) return HMX_EINVAL;
+    hipLaunchKernelGGL(gate_mix_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, z, a, l, g, n, dz, da, dl);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }

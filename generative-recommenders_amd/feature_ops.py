@@ -103,6 +103,32 @@ def sigmoid_gate(p, q):
     return _Gate.apply(p, q)
 
 
+class _GateMix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, a, l):
+        _need_cuda(z, a, l)
+        z, a, l = _f32c(z), _f32c(a), _f32c(l)
+        assert z.shape == a.shape == l.shape
+        out = torch.empty_like(z)
+        hmx.check(_L().hmx_gate_mix_fwd(hmx.ptr(z), hmx.ptr(a), hmx.ptr(l), z.numel(), hmx.ptr(out), _s()), "hmx_gate_mix_fwd")
+        ctx.save_for_backward(z, a, l)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, a, l = ctx.saved_tensors
+        g = _f32c(g)
+        dz, da, dl = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        hmx.check(_L().hmx_gate_mix_bwd(hmx.ptr(z), hmx.ptr(a), hmx.ptr(l), hmx.ptr(g), z.numel(), hmx.ptr(dz), hmx.ptr(da),
+                                        hmx.ptr(dl), _s()), "hmx_gate_mix_bwd")
+        return dz, da, dl
+
+
+def gate_mix(z, a, l):
+    """sigmoid(z) * a + (1 - sigmoid(z)) * l."""
+    return _GateMix.apply(z, a, l)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps):

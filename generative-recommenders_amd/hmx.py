@@ -112,6 +112,8 @@ PROTOTYPES = {
     "hmx_act_bwd": (c_int, [P, P, I64, c_int, P, P]),
     "hmx_gate_fwd": (c_int, [P, P, I64, P, P]),
     "hmx_gate_bwd": (c_int, [P, P, P, I64, P, P, P]),
+    "hmx_gate_mix_fwd": (c_int, [P, P, P, I64, P, P]),
+    "hmx_gate_mix_bwd": (c_int, [P, P, P, P, I64, P, P, P, P]),
     "hmx_layernorm_bwd_blocks": (I64, [I64]),
     "hmx_layernorm_fwd": (c_int, [P, P, P, I64, I64, F, P, P, P, P]),
     "hmx_layernorm_bwd": (c_int, [P, P, P, P, P, I64, I64, P, P, P]),

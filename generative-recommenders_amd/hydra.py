@@ -12,6 +12,7 @@ from torch import nn
 
 from . import block_ops
 from . import enc_ops as E
+from . import feature_ops
 from . import hmx
 from . import ops
 from .enc_ops import pscan, selective_scan   # noqa: F401  (hydra3.py:104, 107: same names, same call shapes)
@@ -160,8 +161,8 @@ class HydraBlock(_HydraBlockBase):
 
 class MultiScaleUserEncoder(nn.Module):
     """hydra3.py:460-548.  The three HydraBlocks, the attention's projections, the one-query attention, the gate's
-    Linear, the RMSNorm and the output projection run on the HIP kernels; the (B, d) elementwise glue of the
-    tail (sigmoid, the convex mix, the final broadcast add) is PyTorch."""
+    Linear, the gated mix, the RMSNorm and the output projection run on the HIP kernels; the final broadcast add
+    over the sequence is PyTorch."""
 
     def __init__(self, dim, dt_rank, dim_inner, d_state, args):
         super().__init__()
@@ -197,11 +198,11 @@ class MultiScaleUserEncoder(nn.Module):
             keep = 1.0 - ca.dropout
             drop = (torch.rand(B, H, L, device=long_.device) < keep).float() / keep
         att = E.linear(E.attn1q(q, kv, drop, L, H), ca.out_proj.weight, ca.out_proj.bias)
-        gate = self.fusion_gate[0]        # Linear(3d -> d) on cat[sf, mf, lf], as three column blocks
-        g = E.linear(sf, gate.weight[:, :d], gate.bias)
-        g = E.linear(mf, gate.weight[:, d:2 * d], None, r1=g, c1=1.0)
-        g = torch.sigmoid(E.linear(lf, gate.weight[:, 2 * d:], None, r1=g, c1=1.0))
-        mixed = g * att + (1 - g) * lf
+        gate = self.fusion_gate[0]        # Linear(3d -> d) on cat[sf, mf, lf], as three column blocks of the weight
+        z = E.linear(sf, gate.weight, gate.bias)
+        z = E.linear(mf, gate.weight, None, r1=z, c1=1.0, col_off=d)
+        z = E.linear(lf, gate.weight, None, r1=z, c1=1.0, col_off=2 * d)
+        mixed = feature_ops.gate_mix(z, att, lf)          # sigmoid(z) * att + (1 - sigmoid(z)) * lf
         fused = E.linear(E.rmsnorm(mixed, self.norm.scale, self.norm.eps), self.output_proj.weight, self.output_proj.bias)
         return long_ + 0.5 * fused.view(B, 1, d)
 

@@ -464,6 +464,13 @@ int hmx_act_bwd(const float* x, const float* g, int64_t n, int mode, float* dx, 
 int hmx_gate_fwd(const float* p, const float* q, int64_t n, float* out, void* stream);
 int hmx_gate_bwd(const float* p, const float* q, const float* g, int64_t n, float* dp, float* dq, void* stream);
 
+/* Gated mix of the multi-scale fusion tail (hydra3.py:536-541: gate = sigmoid(fusion_gate linear); fused = gate *
+ * attended + (1 - gate) * long_term): out = sigmoid(z) * a + (1 - sigmoid(z)) * l in one pass, z = the gate's linear
+ * output.  Backward: dz = g (a - l) s (1 - s), da = g s, dl = g (1 - s) with s = sigmoid(z). */
+int hmx_gate_mix_fwd(const float* z, const float* a, const float* l, int64_t n, float* out, void* stream);
+int hmx_gate_mix_bwd(const float* z, const float* a, const float* l, const float* g, int64_t n, float* dz, float* da,
+                     float* dl, void* stream);
+
 /* nn.LayerNorm over the last dimension (embedding.py:56, :105, :109, :117, :126, :133): biased variance, eps inside
  * the root, y = (x - mean) * rstd * weight + bias; d <= 512.  The forward keeps mean and rstd (T each) for the
  * backward, which writes dx and, per workgroup b < hmx_layernorm_bwd_blocks(T), one partial row
