@@ -402,8 +402,8 @@ __global__ __launch_bounds__(kBlock) void segment_sum_balanced_kernel(Src src, c
 // next kJoinFetch * (groups per wave) head pieces together into LDS, and the first group adds them in order from
 // there (8.4 M Zipf(1.05) ids, 4 M x 64: 696 -> 60 us for this kernel).
 constexpr int kJoinLong = 8;       // further blocks from which the wave-cooperative form is used
-constexpr int kJoinFetch = 16;     // head pieces per lane group and round
-constexpr int kJoinLdsPerWave = 16 * 1024;
+constexpr int kJoinFetch = 8;      // head pieces per lane group and round
+constexpr int kJoinLdsPerWave = 8 * 1024;
 
 template <int VEC, int SB>
 __global__ __launch_bounds__(kBlock) void segment_join_kernel(const uint32_t* __restrict__ skeys, int64_t n, int cpr,
