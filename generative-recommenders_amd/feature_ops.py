@@ -194,7 +194,7 @@ def attention(q, kv, drop, B, Lq, Lk, H):
     return _Attention.apply(q, kv, drop, B, Lq, Lk, H)
 
 
-def linear_any(x2, weight, bias=None, r1=None, col_off=0, cols=None):
+def linear_any(x2, weight, bias=None, r1=None, col_off=0):
     """nn.Linear on a (T, K) input through hmx_linear_f32 (K <= 256); a wider input (the raw multimodal item
     embeddings, 1024 to 4096 columns) is a plain library GEMM and goes to torch's (hipBLASLt)."""
     K = x2.shape[1]

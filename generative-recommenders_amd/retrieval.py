@@ -197,7 +197,7 @@ class ShardedRetriever:
         mine = queries[lo:min(lo + per_group, n_q)]
         out_ids = torch.empty(n_q, k, dtype=torch.int64, device=dev)
         out_sc = torch.empty(n_q, k, dtype=torch.float32, device=dev)
-        flags, pending = [], None
+        flags, flag_queries, pending = [], [], None      # per chunk: 'not proven complete' flags and their query numbers
         for c0 in range(0, per_group, self.chunk):
             qc = min(self.chunk, per_group - c0)
             part = mine[c0:c0 + qc]
@@ -211,15 +211,15 @@ class ShardedRetriever:
             g_ids, w1 = self._all_gather(ids.contiguous())
             g_pk, w2 = self._all_gather(packed)
             if pending is not None:
-                flags.append(self._finish_exchanged(pending, out_ids, out_sc, per_group))
+                flags.append(self._finish_exchanged(pending, out_ids, out_sc, per_group, flag_queries))
             pending = ((w1, w2), g_ids, g_pk, c0, qc)
         if pending is not None:
-            flags.append(self._finish_exchanged(pending, out_ids, out_sc, per_group))
+            flags.append(self._finish_exchanged(pending, out_ids, out_sc, per_group, flag_queries))
         redo = torch.cat(flags).nonzero().flatten() if flags else torch.empty(0, dtype=torch.int64, device=dev)
         # the flags derive from all-gathered data: every rank holds the same list, so the collectives below agree
         self.last_stats["uncertain"] = int(redo.numel())
         if redo.numel():
-            qidx = torch.cat([f_idx for f_idx in self._flag_index]).to(dev)[redo]
+            qidx = torch.cat(flag_queries).to(dev)[redo]
             ids, sc = exact_topk(queries[qidx], k)
             g_ids, w1 = self._all_gather(ids.contiguous())
             g_sc, w2 = self._all_gather(sc.contiguous())
@@ -246,9 +246,9 @@ class ShardedRetriever:
         union = vals.permute(1, 0, 2).reshape(qc, -1)
         return union.topk(k, dim=1).values[:, k - 1].contiguous()
 
-    def _finish_exchanged(self, pending, out_ids, out_sc, per_group):
+    def _finish_exchanged(self, pending, out_ids, out_sc, per_group, flag_queries):
         """Merge one chunk; returns the per-query 'not proven complete' flags of its valid queries (the matching
-        global query numbers are appended to self._flag_index)."""
+        global query numbers are appended to flag_queries)."""
         works, g_ids, g_pk, c0, qc = pending
         for w in works:
             w.wait()
@@ -260,8 +260,6 @@ class ShardedRetriever:
         failed = pk[..., k + 1].amax(0) > 0
         flagged = ~(sc[:, k - 1] > bound) | failed
         n_q = out_ids.shape[0]
-        if c0 == 0:
-            self._flag_index = []
         keep = []
         for g in range(self.G):
             q0 = g * per_group + c0
@@ -270,5 +268,5 @@ class ShardedRetriever:
                 out_ids[q0:q0 + n] = ids[g * qc:g * qc + n]
                 out_sc[q0:q0 + n] = sc[g * qc:g * qc + n]
                 keep.append(flagged[g * qc:g * qc + n])
-                self._flag_index.append(torch.arange(q0, q0 + n))
+                flag_queries.append(torch.arange(q0, q0 + n))
         return torch.cat(keep) if keep else flagged[:0]

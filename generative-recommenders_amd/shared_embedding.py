@@ -55,8 +55,8 @@ class SharedEmbeddingConfig:
 
 
 def _run_layers(layers, x2, training):
-    """An nn.Sequential of Linear / LayerNorm / GELU / ReLU / Dropout / Sigmoid holders applied to (T, K) rows
-    through the HIP ops."""
+    """An nn.Sequential of Linear / LayerNorm / GELU / ReLU / Dropout holders applied to (T, K) rows through the HIP
+    ops (dropout: torch's draw)."""
     for layer in layers:
         if isinstance(layer, nn.Linear):
             x2 = FO.linear_any(x2, layer.weight, layer.bias)
