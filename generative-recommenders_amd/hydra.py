@@ -249,6 +249,17 @@ class HardNegativeMiner:
         return ids
 
 
+def _mine_popular(self, user_embeddings, item_popularity, exclude_items=None):
+    """hydra3.py:1009-1021: top_k ids per user drawn with replacement from softmax(item_popularity) (a sampling
+    step, torch's multinomial)."""
+    B = user_embeddings.shape[0]
+    probs = F.softmax(item_popularity.float(), dim=0)
+    return torch.multinomial(probs, self.top_k * B, replacement=True).view(B, self.top_k)
+
+
+HardNegativeMiner.mine_hard_negatives_popular = _mine_popular
+
+
 def _sample_inbatch_indices_no_self(M, rows, T, device):
     """hydra3.py:817-830."""
     if M - 1 >= 2 ** 31:
@@ -359,14 +370,22 @@ class EnhancedTrainingLoss(nn.Module):
             q_chunk=self.q_chunk, predrawn=predrawn)
         self.adaptive_hard_sampler.update_step()
         if neg_embs is not None and self.ranking_loss_weight != 0.0:
-            u, p, n, lm = user_embs[:, -1], pos_embs[:, -1], neg_embs[:, -1], loss_mask[:, -1]
-            rl = -F.logsigmoid((u * p).sum(-1) - (u * n).sum(-1))
-            total = total + self.ranking_loss_weight * ((rl * lm).sum() / lm.sum())
+            total = total + self.ranking_loss_weight * self.compute_ranking_loss(
+                user_embs[:, -1], pos_embs[:, -1], neg_embs[:, -1], loss_mask[:, -1])
         if self.diversity_loss_weight != 0.0:
-            un = F.normalize(user_embs[:, -1], p=2, dim=1)
-            sim = un @ un.t()
-            total = total + self.diversity_loss_weight * (sim * (1 - torch.eye(sim.shape[0], device=sim.device))).abs().mean()
+            total = total + self.diversity_loss_weight * self.compute_diversity_loss(user_embs[:, -1], item_table)
         return total
+
+    def compute_ranking_loss(self, user_embs, pos_embs, neg_embs, loss_mask):
+        """hydra3.py:1098-1104: BPR-style loss on the last position ((B, d)-sized: plain torch ops)."""
+        rl = -F.logsigmoid((user_embs * pos_embs).sum(-1) - (user_embs * neg_embs).sum(-1))
+        return (rl * loss_mask).sum() / loss_mask.sum()
+
+    def compute_diversity_loss(self, user_embs, item_embs=None):
+        """hydra3.py:1106-1116: mean absolute off-diagonal cosine similarity of the batch's user embeddings."""
+        un = F.normalize(user_embs, p=2, dim=1)
+        sim = un @ un.t()
+        return (sim * (1 - torch.eye(sim.shape[0], device=sim.device))).abs().mean()
 
 
 class Hydra(nn.Module):
@@ -463,6 +482,16 @@ class Hydra(nn.Module):
     def predict(self, log_seqs, seq_feature, mask, seq_timestamp, action_type, dwell_bins):
         """hydra3.py:722-728 (with the dwell_bins argument the reference's call sites pass)."""
         return self.get_user_embedding(log_seqs, seq_feature, mask, seq_timestamp, action_type, dwell_bins)
+
+    def rerank_candidates(self, user_item, seq_feature, mask, ts, action_type, candidate_ids, dwell_bins=None):
+        """hydra3.py:772-788: scores (B, C) of per-user candidate lists (B, C) against the user embedding.  The
+        reference's call leaves out dwell_bins (its log2feats needs it); None stands for all-zero bins."""
+        if dwell_bins is None:
+            dwell_bins = torch.zeros_like(user_item)
+        user = self.get_user_embedding(user_item, seq_feature, mask, ts, action_type, dwell_bins)
+        B, C = candidate_ids.shape
+        rows = self._project_small(self.shared_embeddings.item_emb(candidate_ids.reshape(B * C)))
+        return torch.bmm(user.unsqueeze(1), rows.view(B, C, -1).transpose(1, 2)).squeeze(1)
 
     def prepared_item_table(self, refresh=True):
         """bf16 scoring copy of the item table (rebuilt after every optimizer step while training)."""

@@ -556,3 +556,32 @@ def test_pooled_dropout_draws_one_buffer_and_keeps_the_rate():
     keep = (allv > 0).float().mean().item()
     assert abs(keep - 0.75) < 0.02
     assert torch.allclose(allv[allv > 0], torch.tensor(1.0 / 0.75, device=DEV))
+
+
+def test_rerank_candidates_and_auxiliary_losses():
+    """Hydra.rerank_candidates (hydra3.py:772-788) against the same scores from the oracle's user embedding and
+    table rows; the ranking / diversity terms (hydra3.py:1098-1116) against their formulas on the CPU."""
+    s, p = G.load("g8_log2feats"), "G8_log2feats_d16"
+    m = _model_from(s, p).eval()
+    b = {k: G.t(s, f"{p}/{k}") for k in ("seq", "tok", "ts", "act", "dwell")}
+    B = b["seq"].shape[0]
+    feat = [[] for _ in range(B)]
+    cand = torch.randint(0, int(s[p + "/I"]) + 1, (B, 7), generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        got = m.rerank_candidates(b["seq"].to(DEV), feat, b["tok"].to(DEV), b["ts"].to(DEV), b["act"].to(DEV),
+                                  cand.to(DEV), dwell_bins=b["dwell"].to(DEV))
+    user = G.t(s, p + "/user_emb")
+    table = G.params(s, p)["shared_embeddings.item_emb.weight"]
+    want = torch.einsum("bd,bcd->bc", user, table[cand])
+    close(got, want, 2e-3, 1e-3, "rerank scores")
+    loss = m.enchanced_loss
+    g = torch.Generator().manual_seed(4)
+    u, pe, ne = (torch.randn(5, 16, generator=g) for _ in range(3))
+    lm = torch.tensor([1.0, 1.0, 0.0, 1.0, 1.0])
+    rl = -torch.nn.functional.logsigmoid((u * pe).sum(-1) - (u * ne).sum(-1))
+    G.assert_close(loss.compute_ranking_loss(u.to(DEV), pe.to(DEV), ne.to(DEV), lm.to(DEV)).cpu(), (rl * lm).sum() / lm.sum(),
+                   1e-5, 1e-6)
+    un = torch.nn.functional.normalize(u, dim=1)
+    G.assert_close(loss.compute_diversity_loss(u.to(DEV)).cpu(), ((un @ un.t()) * (1 - torch.eye(5))).abs().mean(), 1e-5, 1e-6)
+    ids = H.HardNegativeMiner(None, table.to(DEV), top_k=4).mine_hard_negatives_popular(u.to(DEV), torch.arange(10.0).to(DEV))
+    assert ids.shape == (5, 4) and int(ids.min()) >= 0 and int(ids.max()) < 10
