@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(const float* __restrict
     }
 }
 
-int ln_blocks(int64_t T) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(T, kBlock / 64), 512)); }
+int ln_blocks(int64_t T) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(T, kBlock / 64), 2048)); }
 
 int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(n, kBlock), kMaxGrid)); }
 
