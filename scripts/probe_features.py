@@ -13,6 +13,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 dev = "cuda"
+if os.environ.get("PROBE_DIRECT", "1") == "1":     # the training loop's gradient modes (bench_train.py uses them too)
+    from generative_recommenders_amd import enc_ops, ops
+    ops.set_fused_table_grad(True)
+    enc_ops.set_direct_param_grad(True)
 ft = {"user_sparse": ["103", "104", "105", "109"], "item_sparse": ["100", "117", "111", "118", "101", "102"],
       "user_array": ["106", "107", "108", "110"], "item_array": [], "user_continual": [], "item_continual": [], "item_emb": ["81"]}
 stats = {k: 1000 + 37 * i for i, k in enumerate(ft["user_sparse"] + ft["item_sparse"] + ft["user_array"])}
