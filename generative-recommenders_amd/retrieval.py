@@ -198,12 +198,21 @@ class ShardedRetriever:
         out_ids = torch.empty(n_q, k, dtype=torch.int64, device=dev)
         out_sc = torch.empty(n_q, k, dtype=torch.float32, device=dev)
         flags, flag_queries, pending = [], [], None      # per chunk: 'not proven complete' flags and their query numbers
-        for c0 in range(0, per_group, self.chunk):
+
+        def start_sampling(c0):
+            """Samples chunk c0 and starts the exchange of the samples (queued ahead of the previous chunk's scoring
+            pass, so that under RCCL the exchange runs while that pass computes)."""
             qc = min(self.chunk, per_group - c0)
             part = mine[c0:c0 + qc]
             if part.shape[0] < qc:       # short last group: zero queries keep the collectives uniform (results dropped)
                 part = torch.cat([part, torch.zeros(qc - part.shape[0], queries.shape[1], dtype=queries.dtype, device=dev)])
             g_thr, w = self._all_gather(sample(part, k).contiguous())
+            return c0, qc, part, g_thr, w
+
+        nxt = start_sampling(0) if per_group > 0 else None
+        while nxt is not None:
+            c0, qc, part, g_thr, w = nxt
+            nxt = start_sampling(c0 + self.chunk) if c0 + self.chunk < per_group else None
             w.wait()
             start = self._combine_samples(g_thr, qc, k)
             ids, sc, bounds, failed = seeded_topk(part, k, start)
