@@ -72,23 +72,6 @@ class GradientSync:
                 off += p.numel()
         return self._flat
 
-    class _Done:
-        def wait(self):
-            return True
-
-    def _launch(self, fn, *tensors):
-        """One collective: asynchronous under RCCL (its own stream; wait() orders the current stream behind it).
-        Under gloo with GPU tensors (tests, rehearsals with several ranks on one GPU) it runs to completion here:
-        gloo's asynchronous form on GPU tensors works from helper threads that synchronise streams, and was seen to
-        lock up with further launches and allocations queued behind it."""
-        t = tensors[0]
-        if t.is_cuda and dist.get_backend(self.group) == "gloo":
-            torch.cuda.synchronize(t.device)
-            fn(*tensors, group=self.group)
-            torch.cuda.synchronize(t.device)
-            return self._Done()
-        return fn(*tensors, group=self.group, async_op=True)
-
     @torch.no_grad()
     def __call__(self) -> None:
         if self.world == 1:
@@ -101,7 +84,7 @@ class GradientSync:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         for p in dense_big:
-            works.append(self._launch(dist.all_reduce, p.grad))
+            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         pending_sparse = [self._sparse_begin(p) for p in sparse]
         flat = self._bucket()
         if flat is not None:
@@ -109,7 +92,7 @@ class GradientSync:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             torch._foreach_copy_(self._views, [p.grad for p in self.small])
-            works.append(self._launch(dist.all_reduce, flat))
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
             w.wait()
         if flat is not None:
@@ -145,8 +128,8 @@ class GradientSync:
             pad_rows[:ids.numel()] = gather(g, ids)
         out_ids = torch.empty(self.world * pad_ids.numel(), dtype=torch.int64, device=g.device)
         out_rows = torch.empty(self.world * pad_rows.shape[0], g.shape[1], dtype=g.dtype, device=g.device)
-        w1 = self._launch(dist.all_gather_into_tensor, out_ids, pad_ids)
-        w2 = self._launch(dist.all_gather_into_tensor, out_rows, pad_rows)
+        w1 = dist.all_gather_into_tensor(out_ids, pad_ids, group=self.group, async_op=True)
+        w2 = dist.all_gather_into_tensor(out_rows, pad_rows, group=self.group, async_op=True)
         self.last_stats[id(p)] = {"rows_sent": int(ids.numel()), "rows_padded": int(pad_ids.numel())}
         return p, ids, out_ids, out_rows, (w1, w2)
 
