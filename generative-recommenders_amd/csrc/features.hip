@@ -184,6 +184,38 @@ __global__ __launch_bounds__(kBlock) void layernorm_fwd_kernel(const float* __re
     }
 }
 
+// ---- 1 / max(|x_t|, eps) per row: F.normalize(p=2) of wide rows, folded into the projection that follows
+// as its input row scale.  One wave per row, 16-byte lanes when the row length allows, eight loads in flight.
+__global__ __launch_bounds__(kBlock) void row_inv_norm_kernel(const float* __restrict__ x, int64_t T, int64_t d,
+                                                              float eps, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t t = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); t < T; t += waves) {
+        const float* row = x + t * d;
+        float s = 0.f;
+        if ((d & 3) == 0) {
+            const float4* r4 = reinterpret_cast<const float4*>(row);
+            const int64_t n4 = d >> 2;
+            int64_t c = lane;
+            for (; c + 64 * 7 < n4; c += 64 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = r4[c + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+            }
+            for (; c < n4; c += 64) {
+                const float4 v = r4[c];
+                s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        } else {
+            for (int64_t c = lane; c < d; c += 64) s += row[c] * row[c];
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[t] = 1.0f / fmaxf(sqrtf(s), eps);
+    }
+}
+
 // dx per row; per-workgroup column partials of dw (first d columns of a partial row) and db (next d columns).
 __global__ __launch_bounds__(kBlock) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ mean_in,
@@ -474,6 +506,17 @@ extern "C" int hmx_layernorm_bwd(const float* x, const float* weight, const floa
     if (T > 0 && (!x || !weight || !mean || !rstd || !dy || !dx)) return HMX_EINVAL;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ln_blocks(T)), dim3(kBlock), 0, (hipStream_t)stream, x, weight, mean,
                        rstd, dy, T, (int)d, dx, part);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_row_inv_norm_f32(const float* x, int64_t T, int64_t d, float eps, float* out, void* stream) {
+    HMX_ENTER();
+    if (T < 0 || d <= 0) return HMX_EINVAL;
+    if (T == 0) return HMX_OK;
+    if (!x || !out) return HMX_EINVAL;
+    const int grid = (int)std::min<int64_t>(hmx_ceil_div(T, kBlock / 64), kMaxGrid);
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, x, T, d, eps, out);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }

@@ -115,6 +115,7 @@ def rmsnorm(x, scale, eps=1e-6):
 # so torch.autograd.grad() does not see these gradients; leave it off there.
 _DIRECT_PARAM_GRAD = False
 _WGRAD_BATCH = 24
+_WGRAD_TILES = 1024      # output tiles one batched launch can hold
 
 
 def set_direct_param_grad(flag=True):
@@ -185,14 +186,17 @@ def _param_grad_target(param):
 
 class _WgradQueue:
     def __init__(self):
-        self.jobs, self.keep, self.targets, self.armed = [], [], set(), False
+        self.jobs, self.keep, self.targets, self.armed, self.tiles = [], [], set(), False, 0
 
     def add(self, dy, dy_off, ldy, x, x_off, ldx, in_mask, T, N, K, dw, dw_off, ldw, db, db_off):
         """dW[dw_off ...] += dY^T X (and dbias += column sums of dY); offsets are in elements."""
         tw = dw.data_ptr() + 4 * dw_off
         tb = db.data_ptr() + 4 * db_off if db is not None else None
-        if tw in self.targets or (tb is not None and tb in self.targets) or len(self.jobs) >= _WGRAD_BATCH:
+        tiles = -(-N // 32) * -(-(K + (tb is not None)) // 32)       # 32 x 32 output tiles, bias as one more column
+        if (tw in self.targets or (tb is not None and tb in self.targets) or len(self.jobs) >= _WGRAD_BATCH
+                or self.tiles + tiles > _WGRAD_TILES):
             self.flush()
+        self.tiles += tiles
         d = hmx.WgradDesc(dy.data_ptr() + 4 * dy_off, ldy, x.data_ptr() + 4 * x_off, ldx,
                           in_mask.data_ptr() if in_mask is not None else None, T, N, K, tw, ldw, tb, 1)
         self.jobs.append(d)
@@ -221,7 +225,7 @@ class _WgradQueue:
         nbytes = _L().hmx_linear_wgrad_batch_workspace_bytes(arr, n)
         ws = workspace(nbytes, self.device)
         rc = _L().hmx_linear_wgrad_batch_f32(arr, n, hmx.ptr(ws), ws.numel(), self.stream)
-        self.jobs, self.keep, self.targets = [], [], set()
+        self.jobs, self.keep, self.targets, self.tiles = [], [], set(), 0
         hmx.check(rc, "hmx_linear_wgrad_batch_f32")
 
 

@@ -4,6 +4,7 @@ CUDA fp32 tensors only; no CPU fallback.
 """
 import torch
 
+from . import enc_ops as E
 from . import hmx, ops
 from .enc_ops import _L, _empty, _s, colsum, linear
 from .ops import _f32c, _i64c, _need_cuda
@@ -194,11 +195,90 @@ def attention(q, kv, drop, B, Lq, Lk, H):
     return _Attention.apply(q, kv, drop, B, Lq, Lk, H)
 
 
-def linear_any(x2, weight, bias=None, r1=None, col_off=0):
-    """nn.Linear on a (T, K) input through hmx_linear_f32 (K <= 256); a wider input (the raw multimodal item
-    embeddings, 1024 to 4096 columns) is a plain library GEMM and goes to torch's (hipBLASLt)."""
-    K = x2.shape[1]
-    if K <= 256:
+def row_inv_norm(x2, eps=1e-12):
+    """1 / max(|x_t|, eps) per row of (T, K) data: the row scale of F.normalize(p=2), used as the input row scale of
+    the projection that follows (no gradient: the rows are input data)."""
+    _need_cuda(x2)
+    x2 = _f32c(x2)
+    out = torch.empty(x2.shape[0], dtype=torch.float32, device=x2.device)
+    hmx.check(_L().hmx_row_inv_norm_f32(hmx.ptr(x2), x2.shape[0], x2.shape[1], float(eps), hmx.ptr(out), _s()),
+              "hmx_row_inv_norm_f32")
+    return out
+
+
+_KCHUNK = 256      # widest reduction of one hmx_linear_f32 launch
+
+
+class _WideLinear(torch.autograd.Function):
+    """y = (x * in_scale) W[:, col_off:col_off + K]^T + b (+ r1) for any K: the reduction runs in column chunks of
+    256, each launch adding onto the one before (fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_scale, r1, col_off):
+        _need_cuda(x, weight)
+        x, w = _f32c(x), _f32c(weight)
+        T, K = x.shape
+        N, ldw = w.shape
+        assert ldw >= col_off + K
+        r1 = _f32c(r1) if r1 is not None else None
+        y = _empty(T, N, like=x)
+        for c0 in range(0, K, _KCHUNK):
+            kc = min(_KCHUNK, K - c0)
+            first = c0 == 0
+            E._linear_raw(hmx.ptr(x) + 4 * c0, K, hmx.ptr(w) + 4 * (col_off + c0), ldw, 1, bias if first else None,
+                          T, N, kc, hmx.ptr(y), N, r1 if first else None, 1.0 if (first and r1 is not None) else 0.0,
+                          in_mask=in_scale, accumulate=not first)
+        ctx.save_for_backward(x, w, in_scale)
+        ctx.col_off = col_off
+        ctx.has_bias = bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, in_scale = ctx.saved_tensors
+        T, K = x.shape
+        N, ldw = w.shape
+        co = ctx.col_off
+        g = _f32c(dy)
+        need = ctx.needs_input_grad
+        dx = dw = db = None
+        if need[0]:
+            if in_scale is not None:
+                raise hmx.HmxError("no gradient with respect to rows that enter a projection through a row scale "
+                                   "(they are input data)")
+            dx = _empty(T, K, like=x)
+            for c0 in range(0, K, _KCHUNK):
+                kc = min(_KCHUNK, K - c0)
+                for n0 in range(0, N, _KCHUNK):
+                    nc = min(_KCHUNK, N - n0)
+                    E._linear_raw(hmx.ptr(g) + 4 * n0, N, hmx.ptr(w) + 4 * (n0 * ldw + co + c0), 1, ldw, None, T, kc, nc,
+                                  hmx.ptr(dx) + 4 * c0, K, accumulate=n0 > 0)
+        want_db = ctx.has_bias and need[2]
+        tw = E._param_grad_target(ctx.wparam) if need[1] else None
+        tb = E._param_grad_target(ctx.bparam) if want_db else None
+        if tw is not None and (tb is not None or not want_db):
+            for c0 in range(0, K, _KCHUNK):
+                kc = min(_KCHUNK, K - c0)
+                E._wgrad_queue.add(g, 0, N, x, c0, K, in_scale, T, N, kc, tw, co + c0, ldw, tb if c0 == 0 else None, 0)
+            want_db = False
+        elif need[1]:
+            dw = torch.zeros_like(w) if ldw > K else torch.empty_like(w)
+            db = _empty(N, like=x) if want_db else None
+            for c0 in range(0, K, _KCHUNK):
+                kc = min(_KCHUNK, K - c0)
+                E._wgrad_raw(hmx.ptr(g) + 0, N, hmx.ptr(x) + 4 * c0, K, in_scale, T, N, kc,
+                             hmx.ptr(dw) + 4 * (co + c0), ldw, db if c0 == 0 else None, x.device)
+            want_db = False
+        if want_db:
+            db = colsum(g)
+        return dx, dw, db, None, (g if need[4] else None), None
+
+
+def linear_any(x2, weight, bias=None, r1=None, col_off=0, in_scale=None):
+    """nn.Linear on a (T, K) input through hmx_linear_f32: one launch for K <= 256, column chunks of 256 added in
+    order for a wider input (the raw multimodal item embeddings, 1024 to 4096 columns).  in_scale (T) multiplies
+    the input rows inside the product."""
+    if x2.shape[1] <= _KCHUNK and in_scale is None:
         return linear(x2, weight, bias, r1=r1, c1=1.0 if r1 is not None else 0.0, col_off=col_off)
-    y = torch.nn.functional.linear(x2, weight[:, col_off:col_off + K], bias)
-    return y if r1 is None else y + r1
+    return _WideLinear.apply(x2, weight, bias, in_scale, r1, int(col_off))

@@ -117,6 +117,7 @@ PROTOTYPES = {
     "hmx_layernorm_bwd_blocks": (I64, [I64]),
     "hmx_layernorm_fwd": (c_int, [P, P, P, I64, I64, F, P, P, P, P]),
     "hmx_layernorm_bwd": (c_int, [P, P, P, P, P, I64, I64, P, P, P]),
+    "hmx_row_inv_norm_f32": (c_int, [P, I64, I64, F, P, P]),
     "hmx_attn_fwd": (c_int, [P, P, P, I64, I64, I64, I64, I64, P, P, P]),
     "hmx_attn_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, P]),
     "hmx_profile_enable": (c_int, [c_int]),

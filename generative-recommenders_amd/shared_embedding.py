@@ -6,8 +6,9 @@ follow embedding.py:12-214, 429-454, 486-652 so that reference checkpoints load 
 unchanged.  Id tables: HIP gather / deterministic scatter-add.  Feature groups (sparse, array, continual,
 interaction, multimodal item embeddings) in the three fusion styles: HIP row gathers, bag sums, projections,
 activations, gates and LayerNorm; the projections of one concatenated input are column blocks of the wide weight
-accumulated in place, so no concatenated tensor is built.  Torch GPU ops that remain: the raw multimodal inputs'
-first projection (K of 1024 to 4096: a plain library GEMM), their L2 normalisation, and the dropout draws.
+accumulated in place, so no concatenated tensor is built.  The raw multimodal inputs (1024 to 4096 columns) enter
+their modality encoder through the same projection kernel in column chunks of 256, their L2 normalisation riding as
+the row scale of that product.  Torch GPU ops that remain: the dropout draws.
 """
 import numpy as np
 import torch
@@ -54,12 +55,12 @@ class SharedEmbeddingConfig:
         args.shared_hidden_units = self.shared_hidden_units
 
 
-def _run_layers(layers, x2, training):
+def _run_layers(layers, x2, training, in_scale=None):
     """An nn.Sequential of Linear / LayerNorm / GELU / ReLU / Dropout holders applied to (T, K) rows through the HIP
-    ops (dropout: torch's draw)."""
-    for layer in layers:
+    ops (dropout: torch's draw).  in_scale (T): row scale of the input, applied inside the first projection."""
+    for i, layer in enumerate(layers):
         if isinstance(layer, nn.Linear):
-            x2 = FO.linear_any(x2, layer.weight, layer.bias)
+            x2 = FO.linear_any(x2, layer.weight, layer.bias, in_scale=in_scale if i == 0 else None)
         elif isinstance(layer, nn.LayerNorm):
             x2 = FO.layernorm(x2, layer.weight, layer.bias, layer.eps)
         elif isinstance(layer, nn.GELU):
@@ -91,8 +92,12 @@ class ModalitySpecificEncoder(nn.Module):
             layers = [nn.Linear(input_dim, h), nn.LayerNorm(h), nn.ReLU(), nn.Linear(h, h)]
         self.encoder = nn.Sequential(*layers)
 
-    def forward(self, x):
-        y = _run_layers(self.encoder, x.reshape(-1, x.shape[-1]), self.training)
+    def forward(self, x, normalize_input=False):
+        """normalize_input: encode x / max(|x|, 1e-12) (F.normalize over the last axis) without writing it: the row
+        scale rides in the first projection."""
+        x2 = x.reshape(-1, x.shape[-1])
+        scale = FO.row_inv_norm(x2) if normalize_input else None
+        y = _run_layers(self.encoder, x2, self.training, scale)
         return y.view(*x.shape[:-1], y.shape[-1])
 
 
@@ -357,8 +362,7 @@ class SharedEmbeddingModule(nn.Module):
         pieces, modalities = [], []
         for kind, k in self._groups(include_user, interaction=include_user):
             if kind == 'item_emb':
-                x = torch.nn.functional.normalize(self._dense_input(k, feature_array), p=2, dim=-1)
-                modalities.append(self.emb_transform[k](x))
+                modalities.append(self.emb_transform[k](self._dense_input(k, feature_array), normalize_input=True))
             elif kind == 'continual':
                 lin = self.feature_projections[k]
                 pieces.append(E.linear(self._raw_rows(kind, k, feature_array), lin.weight, lin.bias))

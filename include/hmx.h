@@ -481,6 +481,12 @@ int hmx_layernorm_fwd(const float* x, const float* weight, const float* bias, in
 int hmx_layernorm_bwd(const float* x, const float* weight, const float* mean, const float* rstd, const float* dy,
                       int64_t T, int64_t d, float* dx, float* part, void* stream);
 
+/* out[t] = 1 / max(|x_t|_2, eps) for the rows of x (T, d): the row scale of F.normalize(x, p=2, dim=-1)
+ * (embedding.py:575, the raw multimodal item vectors before their modality encoder).  The caller hands it to
+ * hmx_linear_f32 / the weight-gradient calls as in_rowmask, so the normalised copy of the wide rows is never
+ * written. */
+int hmx_row_inv_norm_f32(const float* x, int64_t T, int64_t d, float eps, float* out, void* stream);
+
 /* Attention core of nn.MultiheadAttention(batch_first=True) as the cross-modal fusion uses it (embedding.py:48-53,
  * :76-78: query = one modality's sequence, key = value = another's; no masks).  q (B * Lq, d) and kv (B * Lk, 2 d) =
  * [k | v] are the ALREADY PROJECTED inputs (in_proj through hmx_linear_f32), heads are column blocks of d / H:

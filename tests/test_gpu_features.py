@@ -138,6 +138,40 @@ def test_projection_column_blocks_and_unit_width_input():
     close(b1d.grad, b1r.grad, 8e-3, 6.5e-3, "K = 1 db")
 
 
+@pytest.mark.parametrize("T,K,N,scaled", [(77, 1024, 128, True), (300, 3584, 64, True), (33, 4096, 256, False),
+                                          (50, 300, 96, False), (19, 32, 64, True), (5, 1027, 32, True)])
+def test_wide_projection_in_column_chunks(T, K, N, scaled):
+    """nn.Linear with more than 256 input columns (raw multimodal item vectors): chunks of 256 columns added launch
+    by launch, the F.normalize of the rows carried as a row scale; autograd accumulation and the direct gradient
+    mode give the same parameter gradients."""
+    g = torch.Generator().manual_seed(T + K)
+    x = torch.randn(T, K, generator=g) * 2
+    if scaled:
+        x[0] = 0                                                  # a zero row stays zero (eps clamp)
+    W, b, G_ = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(T, N, generator=g)
+    Wr, br, xr = W.double().requires_grad_(), b.double().requires_grad_(), x.double().requires_grad_()
+    xin = torch.nn.functional.normalize(xr, p=2, dim=-1) if scaled else xr
+    want = torch.nn.functional.linear(xin, Wr, br)
+    want.backward(G_.double())
+    if scaled:
+        inv = FO.row_inv_norm(x.to(DEV))
+        G.assert_close(inv.cpu(), 1.0 / x.norm(dim=1).clamp_min(1e-12), 1e-5, 0, "row scale")
+    for direct in (False, True):
+        Wd, bd = W.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        xd = x.to(DEV).requires_grad_(not scaled)
+        E.set_direct_param_grad(direct)
+        try:
+            y = FO.linear_any(xd, Wd, bd, in_scale=FO.row_inv_norm(xd.detach()) if scaled else None)
+            y.backward(G_.to(DEV))
+        finally:
+            E.set_direct_param_grad(False)
+        close(y, want.float(), 2e-3, 1e-3, "wide")
+        close(Wd.grad, Wr.grad.float(), 8e-3, 6.5e-3, f"wide dW direct={direct}")
+        close(bd.grad, br.grad.float(), 8e-3, 6.5e-3, f"wide db direct={direct}")
+        if not scaled:
+            close(xd.grad, xr.grad.float(), 4e-3, 2.5e-3, "wide dx")
+
+
 def _module(s, p):
     se, args = feature_module_from(s, p, SE.SharedEmbeddingModule, device=DEV)
     return se, args
