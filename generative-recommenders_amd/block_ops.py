@@ -205,8 +205,8 @@ class drop_pool:
 
     def __enter__(self):
         if self.enabled:
-            keep = 1.0 - self.p
-            self.buf = torch.empty(self.n, dtype=torch.float32, device=self.device).bernoulli_(keep).mul_(1.0 / keep)
+            from .feature_ops import dropout_multiplier
+            self.buf = dropout_multiplier((self.n,), self.p, self.device)
             self.prev, drop_pool._active = drop_pool._active, self
         return self
 
@@ -223,7 +223,8 @@ class drop_pool:
             out = pool.buf[pool.at:pool.at + n].view(T, d)
             pool.at += (n + 3) // 4 * 4
             return out
-        return torch.empty(T, d, dtype=torch.float32, device=device).bernoulli_(1.0 - pdrop).mul_(1.0 / (1.0 - pdrop))
+        from .feature_ops import dropout_multiplier
+        return dropout_multiplier((T, d), pdrop, device)
 
 
 def hydra_block(blk, x2, mask1, L, first):

@@ -184,6 +184,42 @@ __global__ __launch_bounds__(kBlock) void layernorm_fwd_kernel(const float* __re
     }
 }
 
+// ---- dropout multipliers: out[i] = 0 with probability p_drop, else 1 / (1 - p_drop) ---------------------
+// Philox4x32-10 keyed by the caller's seed; counter = (block of four outputs, stream offset).  One counter yields four
+// 32-bit words = four outputs, so a thread writes 16 bytes; the value of out[i] depends on (seed, offset, i) only.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+
+__global__ __launch_bounds__(kBlock) void dropout_multiplier_kernel(uint64_t seed, uint64_t offset, int64_t n, float keep,
+                                                                    float scale, float* __restrict__ out) {
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < n4; b += (int64_t)gridDim.x * kBlock) {
+        uint32_t c[4] = {(uint32_t)b, (uint32_t)((uint64_t)b >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)(c[j] >> 8) * (1.0f / 16777216.0f) < keep ? scale : 0.f;
+        const int64_t i = b << 2;
+        if (i + 4 <= n && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+            *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int j = 0; j < 4 && i + j < n; ++j) out[i + j] = v[j];
+        }
+    }
+}
+
 // ---- 1 / max(|x_t|, eps) per row: F.normalize(p=2) of wide rows, folded into the projection that follows
 // as its input row scale.  One wave per row, 16-byte lanes when the row length allows, eight loads in flight.
 __global__ __launch_bounds__(kBlock) void row_inv_norm_kernel(const float* __restrict__ x, int64_t T, int64_t d,
@@ -506,6 +542,20 @@ extern "C" int hmx_layernorm_bwd(const float* x, const float* weight, const floa
     if (T > 0 && (!x || !weight || !mean || !rstd || !dy || !dx)) return HMX_EINVAL;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(ln_blocks(T)), dim3(kBlock), 0, (hipStream_t)stream, x, weight, mean,
                        rstd, dy, T, (int)d, dx, part);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_dropout_multiplier_f32(uint64_t seed, uint64_t offset, int64_t n, float p_drop, float* out,
+                                          void* stream) {
+    HMX_ENTER();
+    if (n < 0 || !(p_drop >= 0.f && p_drop <= 1.f)) return HMX_EINVAL;
+    if (n == 0) return HMX_OK;
+    if (!out) return HMX_EINVAL;
+    const float keep = 1.0f - p_drop;
+    const float scale = keep > 0.f ? 1.0f / keep : 0.f;
+    hipLaunchKernelGGL(dropout_multiplier_kernel, dim3(grid_for((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, seed,
+                       offset, n, keep, scale, out);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }

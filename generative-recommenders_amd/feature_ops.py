@@ -195,6 +195,28 @@ def attention(q, kv, drop, B, Lq, Lk, H):
     return _Attention.apply(q, kv, drop, B, Lq, Lk, H)
 
 
+def dropout_multiplier(shape, p_drop, device):
+    """Tensor of `shape` holding 0 with probability p_drop and 1 / (1 - p_drop) otherwise (what nn.Dropout multiplies
+    its input by in training).  The Philox seed of a draw comes from torch's CPU generator, so torch.manual_seed
+    makes a run repeatable; no gradient (a constant of the step)."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise hmx.HmxError("dropout_multiplier: the HIP kernels need a GPU device")
+    out = torch.empty(shape, dtype=torch.float32, device=dev)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())        # a fresh key per draw; the stream offset stays 0
+    with torch.cuda.device(dev):
+        hmx.check(_L().hmx_dropout_multiplier_f32(seed, 0, out.numel(), float(p_drop), hmx.ptr(out), _s()),
+                  "hmx_dropout_multiplier_f32")
+    return out
+
+
+def dropout(x, p_drop, training):
+    """nn.Dropout / F.dropout on (.., d) rows: x times a drawn multiplier (identity in eval mode or at p = 0)."""
+    if not training or p_drop <= 0.0:
+        return x
+    return E.mul_scale(x, dropout_multiplier(x.shape, p_drop, x.device), 1.0)
+
+
 def row_inv_norm(x2, eps=1e-12):
     """1 / max(|x_t|, eps) per row of (T, K) data: the row scale of F.normalize(p=2), used as the input row scale of
     the projection that follows (no gradient: the rows are input data)."""

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "hmx_layernorm_fwd": (c_int, [P, P, P, I64, I64, F, P, P, P, P]),
     "hmx_layernorm_bwd": (c_int, [P, P, P, P, P, I64, I64, P, P, P]),
     "hmx_row_inv_norm_f32": (c_int, [P, I64, I64, F, P, P]),
+    "hmx_dropout_multiplier_f32": (c_int, [ctypes.c_uint64, ctypes.c_uint64, I64, F, P, P]),
     "hmx_attn_fwd": (c_int, [P, P, P, I64, I64, I64, I64, I64, P, P, P]),
     "hmx_attn_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, P]),
     "hmx_profile_enable": (c_int, [c_int]),

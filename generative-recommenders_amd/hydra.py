@@ -136,7 +136,7 @@ class _HydraBlockBase(nn.Module):
         if FUSED_BLOCKS and x2.is_cuda and hmx.SPLIT_BF16 and block_ops.supported(d, len(mhm.mamba)):
             # the block as two fused token-parallel kernels around the conv / scan core
             return block_ops.hydra_block(self, x2.contiguous(), m1, L, self.first).view(B, L, d)
-        n = E.rmsnorm(self.dropout(x2), self.norm1.scale, self.norm1.eps)
+        n = E.rmsnorm(feature_ops.dropout(x2, self.dropout.p, self.training), self.norm1.scale, self.norm1.eps)
         p = mhm.mix(n, m1, L)
         # mixer output x_org + W2 p + b2, plus the block's residual: n (first block) or x again (regular block)
         if self.first:
@@ -195,8 +195,7 @@ class MultiScaleUserEncoder(nn.Module):
         kv = E.linear(long_.reshape(B * L, d), W[d:], bias[d:])
         drop = None
         if self.training and ca.dropout > 0.0:
-            keep = 1.0 - ca.dropout
-            drop = (torch.rand(B, H, L, device=long_.device) < keep).float() / keep
+            drop = feature_ops.dropout_multiplier((B, H, L), ca.dropout, long_.device)
         att = E.linear(E.attn1q(q, kv, drop, L, H), ca.out_proj.weight, ca.out_proj.bias)
         gate = self.fusion_gate[0]        # Linear(3d -> d) on cat[sf, mf, lf], as three column blocks of the weight
         z = E.linear(sf, gate.weight, gate.bias)

@@ -8,7 +8,7 @@ interaction, multimodal item embeddings) in the three fusion styles: HIP row gat
 activations, gates and LayerNorm; the projections of one concatenated input are column blocks of the wide weight
 accumulated in place, so no concatenated tensor is built.  The raw multimodal inputs (1024 to 4096 columns) enter
 their modality encoder through the same projection kernel in column chunks of 256, their L2 normalisation riding as
-the row scale of that product.  Torch GPU ops that remain: the dropout draws.
+the row scale of that product; dropout multipliers come from the library's Philox kernel.
 """
 import numpy as np
 import torch
@@ -57,7 +57,7 @@ class SharedEmbeddingConfig:
 
 def _run_layers(layers, x2, training, in_scale=None):
     """An nn.Sequential of Linear / LayerNorm / GELU / ReLU / Dropout holders applied to (T, K) rows through the HIP
-    ops (dropout: torch's draw).  in_scale (T): row scale of the input, applied inside the first projection."""
+    ops.  in_scale (T): row scale of the input, applied inside the first projection."""
     for i, layer in enumerate(layers):
         if isinstance(layer, nn.Linear):
             x2 = FO.linear_any(x2, layer.weight, layer.bias, in_scale=in_scale if i == 0 else None)
@@ -68,7 +68,7 @@ def _run_layers(layers, x2, training, in_scale=None):
         elif isinstance(layer, nn.ReLU):
             x2 = FO.relu(x2)
         elif isinstance(layer, nn.Dropout):
-            x2 = torch.nn.functional.dropout(x2, layer.p, training)
+            x2 = FO.dropout(x2, layer.p, training)
         else:
             raise TypeError(f"unexpected layer {type(layer).__name__}")
     return x2
@@ -135,7 +135,7 @@ class CrossModalFusionLayer(nn.Module):
         kv = E.linear(tgt2, mha.in_proj_weight[d:], mha.in_proj_bias[d:])
         drop = None
         if self.training and mha.dropout > 0:      # the multiplier nn.MultiheadAttention applies to its weights
-            drop = torch.nn.functional.dropout(torch.ones(B, H, L, L, device=q.device), mha.dropout, True)
+            drop = FO.dropout_multiplier((B, H, L, L), mha.dropout, q.device)
         ctxv = FO.attention(q, kv, drop, B, L, L, H)
         return E.linear(ctxv, mha.out_proj.weight, mha.out_proj.bias)
 

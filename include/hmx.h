@@ -481,6 +481,12 @@ int hmx_layernorm_fwd(const float* x, const float* weight, const float* bias, in
 int hmx_layernorm_bwd(const float* x, const float* weight, const float* mean, const float* rstd, const float* dy,
                       int64_t T, int64_t d, float* dx, float* part, void* stream);
 
+/* Dropout multipliers (nn.Dropout at hydra3.py:411,445 and embedding.py:107,119; the attention-weight dropout of
+ * nn.MultiheadAttention at hydra3.py:484 and embedding.py:51): out[i] = 0 with probability p_drop, else
+ * 1 / (1 - p_drop); the consumer multiplies.  Philox4x32-10: out[i] is a function of (seed, offset, i) alone, so a
+ * draw can be repeated; callers advance `offset` (any value) or change `seed` between draws.  0 <= p_drop <= 1. */
+int hmx_dropout_multiplier_f32(uint64_t seed, uint64_t offset, int64_t n, float p_drop, float* out, void* stream);
+
 /* out[t] = 1 / max(|x_t|_2, eps) for the rows of x (T, d): the row scale of F.normalize(x, p=2, dim=-1)
  * (embedding.py:575, the raw multimodal item vectors before their modality encoder).  The caller hands it to
  * hmx_linear_f32 / the weight-gradient calls as in_rowmask, so the normalised copy of the wide rows is never

@@ -172,6 +172,55 @@ def test_wide_projection_in_column_chunks(T, K, N, scaled):
             close(xd.grad, xr.grad.float(), 4e-3, 2.5e-3, "wide dx")
 
 
+@pytest.mark.parametrize("n,p", [(1, 0.5), (7, 0.2), (4096, 0.2), (1000003, 0.3), (65536, 0.0), (1001, 1.0)])
+def test_dropout_multiplier(n, p):
+    """Values are 0 or 1 / (1 - p), the kept fraction is 1 - p within five standard deviations, a draw repeats under
+    the same torch seed and differs under another, and consecutive draws differ."""
+    torch.manual_seed(11)
+    a = FO.dropout_multiplier((n,), p, DEV)
+    b = FO.dropout_multiplier((n,), p, DEV)
+    torch.manual_seed(11)
+    a2 = FO.dropout_multiplier((n,), p, DEV)
+    torch.manual_seed(12)
+    c = FO.dropout_multiplier((n,), p, DEV)
+    assert torch.equal(a, a2)
+    keep = 1.0 - p
+    scale = np.float32(1.0) / np.float32(keep) if keep > 0 else 0.0
+    vals = set(a.unique().tolist())
+    assert vals <= {0.0, float(scale)}
+    if p in (0.0, 1.0):
+        assert float(a.sum()) == (n if p == 0.0 else 0.0)
+        return
+    if n >= 4096:
+        frac = float((a > 0).float().mean())
+        assert abs(frac - keep) < 5 * (keep * p / n) ** 0.5
+        assert not torch.equal(a, b) and not torch.equal(a, c)
+        # neighbours are independent: the kept fraction among elements that follow a kept one is 1 - p as well
+        k = a > 0
+        both = float((k[1:] & k[:-1]).float().mean())
+        assert abs(both - keep * keep) < 6 * (keep * keep * (1 - keep * keep) / n) ** 0.5
+    # an unaligned view (odd element offset) takes the scalar store path and holds the same stream
+    buf = torch.zeros(n + 1, device=DEV)
+    from generative_recommenders_amd import hmx as HM
+    HM.check(HM.lib().hmx_dropout_multiplier_f32(123, 5, n, p, buf[1:].data_ptr(), None), "dropout")
+    ref = torch.zeros(n, device=DEV)
+    HM.check(HM.lib().hmx_dropout_multiplier_f32(123, 5, n, p, ref.data_ptr(), None), "dropout")
+    torch.cuda.synchronize()
+    assert torch.equal(buf[1:], ref) and float(buf[0]) == 0.0
+
+
+def test_dropout_rows_forward_backward():
+    x = torch.randn(300, 64, device=DEV, requires_grad=True)
+    assert FO.dropout(x, 0.2, False) is x and FO.dropout(x, 0.0, True) is x
+    torch.manual_seed(3)
+    y = FO.dropout(x, 0.2, True)
+    torch.manual_seed(3)
+    m = FO.dropout_multiplier(x.shape, 0.2, DEV)
+    g = torch.randn_like(x)
+    y.backward(g)
+    assert torch.equal(y.detach(), x.detach() * m) and torch.equal(x.grad, g * m)
+
+
 def _module(s, p):
     se, args = feature_module_from(s, p, SE.SharedEmbeddingModule, device=DEV)
     return se, args
