@@ -2,7 +2,7 @@
 a thread, the all_gather is a hand-over between the threads, and only one thread runs at a time (the library's
 workspace is shared).  Odd shapes: ranges shorter than k, empty trailing ranges, ragged last query group, one query,
 k = 1 and k = 16, d = 128.  The result must equal the unsharded kernel's (itself pinned to the C oracle), and the
-oracle's on a slice."""
+oracle's on a slice.  GradientSync's exchange runs the same way for 4 and 8 ranks."""
 import threading
 
 import numpy as np
@@ -111,3 +111,87 @@ def test_rank_grid_in_one_process(rows, n_q, k, d, world, item_shards, chunk):
     assert np.array_equal(results[0][0][sl].cpu().numpy(), o_ids) and np.array_equal(results[0][1][sl].cpu().numpy(), o_sc)
     if n_q >= 262_144:
         assert results[0][2]["uncertain"] < n_q // 50
+
+
+class _FakeDist:
+    """What parallel.py uses of torch.distributed, carried by a _Grid (the calling rank is the thread's)."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def __init__(self, grid):
+        self.grid, self.local = grid, threading.local()
+
+    def is_initialized(self):
+        return True
+
+    def get_world_size(self, group=None):
+        return self.grid.world
+
+    def all_gather_into_tensor(self, out, t, group=None, async_op=False):
+        got, done = self.grid.gather(self.local.rank, t)
+        out.copy_(got.reshape(out.shape))
+        return done
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        got, done = self.grid.gather(self.local.rank, t.clone())
+        total = got[0].clone()
+        for r in range(1, self.grid.world):            # rank order: every rank ends with the same bits
+            total += got[r]
+        t.copy_(total)
+        return done
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_gradient_sync_on_a_rank_grid_in_one_process(world, monkeypatch):
+    """GradientSync's own code for 4 and 8 ranks on one GPU (ranks are threads, collectives are hand-overs): the sparse
+    (row id, row) exchange on the HIP row gather + deterministic scatter-add equals the dense all-reduce, every rank
+    ends with identical bits, and ranks that touched no row, one row, or the same rows as a neighbour take part."""
+    from generative_recommenders_amd import parallel
+    grid = _Grid(world)
+    fake = _FakeDist(grid)
+    monkeypatch.setattr(parallel, "dist", fake)
+    g = torch.Generator().manual_seed(world)
+    rows, d = 20_000, 64
+    table0 = torch.randn(rows, d, generator=g).cuda()
+    w0 = torch.randn(d, d, generator=g).cuda()
+    counts = [3000, 0, 1, 3000, 17, 2500, 1, 999][:world]
+    id_sets = [torch.randint(0, rows, (n,), generator=g).cuda() for n in counts]
+    id_sets[3] = id_sets[0].clone()                         # two ranks touching exactly the same rows
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        grid.turn.acquire()
+        fake.local.rank = rank
+        try:
+            out = {}
+            for name, sparse in (("sparse", True), ("dense", False)):
+                table, w = torch.nn.Parameter(table0.clone()), torch.nn.Parameter(w0.clone())
+                ids = id_sets[rank]
+                if ids.numel():
+                    loss = ((ops.gather_rows(table, ids) @ w) ** 2).mean() * (rank + 1)
+                    loss.backward()
+                sync = parallel.GradientSync([table, w], big_bytes=1 << 20, sparse_tables=sparse)
+                sync()
+                out[name] = (table.grad.clone(), w.grad.clone())
+            results[rank] = out
+        except BaseException as e:                               # noqa: BLE001 - reported by the main thread
+            errors.append((rank, repr(e)))
+            grid.barrier.abort()
+        finally:
+            grid.turn.release()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for name in ("sparse", "dense"):
+        for r in range(1, world):
+            assert torch.equal(results[r][name][0], results[0][name][0]), (name, r)
+            assert torch.equal(results[r][name][1], results[0][name][1]), (name, r)
+    torch.testing.assert_close(results[0]["sparse"][0], results[0]["dense"][0], rtol=1e-5, atol=1e-7)
+    assert torch.equal(results[0]["sparse"][1], results[0]["dense"][1])
+    touched = torch.cat(id_sets).unique()
+    assert int((results[0]["sparse"][0].abs().sum(1) > 0).sum()) == touched.numel()
