@@ -1188,7 +1188,11 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
     pl.chunk = std::min<int64_t>(hmx_ceil_div(n_q, qpw) * qpw, 2048 * qpw);
     if (ring_shape(bf16, pl.NB, pl.KS, n_q)) pl.chunk = hmx_ceil_div(pl.chunk, qpw * kRingWaves) * qpw * kRingWaves;
     pl.n_qtiles = (int)(pl.chunk / (32 * pl.NB));
-    int64_t s = hmx_ceil_div(2048, pl.n_qtiles);
+    // Item splits fill the chip's 2048 wave slots (256 CUs x 8) without exceeding them: one wave more than a full
+    // round costs a second round, and a launch of more than half the slots' query tiles stays at ONE split, the only
+    // shape whose start thresholds are sampled (a 213,568-query tail of a sharded search took 50.8 ms in two cold
+    // splits against 12.5 ms for a full 262,144-query launch of the same 500 K-row range).
+    int64_t s = std::max<int64_t>(1, 2048 / pl.n_qtiles);
     s = std::min<int64_t>(s, 8192 / (2 * pl.KP));              // candidates per query <= 8192
     s = std::min<int64_t>(s, std::max<int64_t>(1, n_rows / 256));     // at least eight tiles per wave
     if (s >= 8) s = s / 8 * 8;                                  // XCD-aware block mapping wants a multiple of 8
@@ -1322,15 +1326,16 @@ bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, To
     tp.cand_bytes = tp.full.cand_bytes;
     tp.meta_bytes = tp.full.meta_bytes;
     if (!bf16) return true;
-    // Seeding pays when every wave of the full pass covers only a slice of the table (few queries, many item
-    // splits): there the cold start is most of a wave's life.  With >= 64 K queries per launch each wave walks
-    // the whole table and the extra re-score passes cost more than the cold start they remove.
+    // Seeding pays whenever the full pass is cut into item splits (launches of up to half the chip's wave slots in
+    // query tiles): such a pass has no sampled start, and its cold start costs more than the prefix passes
+    // (whole table, top-10, ms per launch cold -> seeded: 40,000 queries 39.8 -> 19.0, 65,536 49.4 -> 29.5,
+    // 100,000 69.0 -> 50.3, 131,072 73.9 -> 59.0).  One-split launches start from sampled thresholds instead.
     int64_t rows[kMaxSeedLevels];
     static const bool seed_on = [] {
         const char* e = getenv("HMX_TOPK_SEED");
         return e == nullptr || e[0] != '0';
     }();
-    const int n = (tp.full.n_splits >= 8 && seed_on) ? seed_levels(n_rows, tp.full.KP, rows) : 0;
+    const int n = (tp.full.n_splits >= 2 && seed_on) ? seed_levels(n_rows, tp.full.KP, rows) : 0;
     for (int i = 0; i < n; ++i) {
         Plan ps;
         if (!make_plan(n_q, rows[i], d, k, true, ps) || ps.chunk != tp.full.chunk) {
