@@ -1233,9 +1233,9 @@ bool make_plan(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, Pla
     if (ring_shape(bf16, pl.NB, pl.KS, n_q)) pl.chunk = hmx_ceil_div(pl.chunk, qpw * kRingWaves) * qpw * kRingWaves;
     pl.n_qtiles = (int)(pl.chunk / (32 * pl.NB));
     // Item splits fill the chip's 2048 wave slots (256 CUs x 8) without exceeding them: one wave more than a full
-    // round costs a second round, and a launch of more than half the slots' query tiles stays at ONE split, the only
-    // shape whose start thresholds are sampled (a 213,568-query tail of a sharded search took 50.8 ms in two cold
-    // splits against 12.5 ms for a full 262,144-query launch of the same 500 K-row range).
+    // round costs a second round, and a launch of more than half the slots' query tiles stays at one split (a
+    // 213,568-query tail of a sharded search took 50.8 ms in two cold splits against 12.5 ms for a full
+    // 262,144-query launch of the same 500 K-row range).
     int64_t s = std::max<int64_t>(1, 2048 / pl.n_qtiles);
     s = std::min<int64_t>(s, 8192 / (2 * pl.KP));              // candidates per query <= 8192
     s = std::min<int64_t>(s, std::max<int64_t>(1, n_rows / 256));     // at least eight tiles per wave
@@ -1355,6 +1355,13 @@ int seed_levels(int64_t n_rows, int KP, int64_t* sample_rows) {
     return n;
 }
 
+// Launch shapes whose start thresholds are sampled (warm_threshold_kernel) or taken from the caller: top-16 or less
+// in at most four item splits, i.e. launches of 512 query tiles or more.  Every split starts from the query's one
+// sampled threshold.  Whole table, top-10, ms per launch seeded -> sampled: 131,072 queries (2 splits) 61.2 -> 54.5,
+// 100,000 (2) 52.3 -> 48.8, 65,536 (4) 30.3 -> 29.1; at 5 to 7 splits the two are equal and the prefixes stay.
+constexpr int kSampleMaxSplits = 4;
+bool sampled_start(const Plan& pl) { return pl.KP == 32 && pl.n_splits <= kSampleMaxSplits && warm_enabled(); }
+
 struct TopkPlans {
     Plan full;
     Plan seed[kMaxSeedLevels];
@@ -1379,7 +1386,8 @@ bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, To
         const char* e = getenv("HMX_TOPK_SEED");
         return e == nullptr || e[0] != '0';
     }();
-    const int n = (tp.full.n_splits >= 2 && seed_on) ? seed_levels(n_rows, tp.full.KP, rows) : 0;
+    const bool sampled = sampled_start(tp.full);
+    const int n = (tp.full.n_splits >= 2 && !sampled && seed_on) ? seed_levels(n_rows, tp.full.KP, rows) : 0;
     for (int i = 0; i < n; ++i) {
         Plan ps;
         if (!make_plan(n_q, rows[i], d, k, true, ps) || ps.chunk != tp.full.chunk) {
@@ -1507,7 +1515,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             return HMX_OK;
         };
         const float* thr0 = nullptr;
-        const bool samples = bf16 && tp.n_seed == 0 && pl.KP == 32 && pl.n_splits == 1 && warm_enabled();
+        const bool samples = bf16 && tp.n_seed == 0 && sampled_start(pl);
         if (sample_out != nullptr && !samples) {
             hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)hmx_ceil_div(nq * sample_values, 256)), dim3(256), 0, s,
                                sample_out + q0 * sample_values, nq * sample_values, kNegInf);

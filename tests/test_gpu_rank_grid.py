@@ -87,6 +87,8 @@ CASES = [
     (40_001, 20_000, 16, 64, 3, 3, 8192),              # k = 16
     (30_001, 262_144, 10, 128, 4, 4, 262_144),         # d = 128, sampled + exchanged
     (40_001, 5000, 50, 64, 2, 2, 2048),                # the miner's k on ranges
+    (60_003, 100_000, 10, 64, 2, 2, 131_072),          # launches cut into two item splits: still sampled + exchanged
+    (60_003, 50_000, 10, 64, 3, 3, 65_536),            # five item splits: seeded from table prefixes, nothing to exchange
     (4_000_001, 1_000_000, 10, 64, 8, 8, 262_144),     # the full sharded retrieval: 4 M items in eight ranges, 1 M queries
 ]
 
