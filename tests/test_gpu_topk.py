@@ -299,3 +299,21 @@ def test_threshold_exchange_between_item_ranges(stress, d):
     for sl in (slice(0, 32), slice(1000, 1032)):
         o_ids, o_sc = C.score_topk(q[sl].numpy(), table.numpy(), k)
         assert np.array_equal(ids[sl].cpu().numpy(), o_ids) and np.array_equal(sc[sl].cpu().numpy(), o_sc)
+
+
+@pytest.mark.parametrize("nq,rows,d,k", [(40_000, 70_001, 64, 10), (100_000, 70_001, 64, 10), (131_072, 30_001, 64, 16),
+                                         (150_000, 5000, 64, 16), (70_000, 5000, 128, 16), (100_000, 70_001, 128, 50)])
+def test_launches_between_the_plan_switch_points(nq, rows, d, k):
+    """Launches of 16 K to 262 K queries: six, two and one item splits (seeded from table prefixes, sampled start for
+    two splits, sampled start for one), short tables, d = 128, with a block of near-duplicate rows that sends some
+    queries to the exact re-run.  All queries equal the exact fp32 kernel, a slice equals the C oracle."""
+    g = torch.Generator().manual_seed(nq + rows)
+    t = torch.randn(rows, d, generator=g)
+    t[100:140] = t[100] + 1e-4 * torch.randn(40, d, generator=g)
+    q = torch.randn(nq, d, generator=g)
+    q[:7] = t[100] * 3
+    tq, qq = t.to(DEV), q.to(DEV)
+    ids, sc = ops.score_topk(qq, ops.PreparedTable(tq), k)
+    want_ids, want_sc = ops.score_topk_exact(qq, tq, k)
+    assert torch.equal(ids, want_ids) and torch.equal(sc, want_sc)
+    _check(ids[:24], sc[:24], q[:24], t, k)
