@@ -135,6 +135,45 @@ int launch_gather(const float* t0, int64_t r0, const float* t1, int64_t r1, int6
     return HMX_OK;
 }
 
+// flags[r] = 1 when row r of x (n_rows, d) holds a value != 0 (NaN counts), else 0: which rows of a dense table
+// gradient a step touched.  A group of 2^lpr_log2 lanes owns a row (16-byte lanes when d % 4 == 0), four rows per
+// group in flight, the group's verdict taken from one wave ballot; every lane stays in the loop (uniform trip count).
+template <bool VEC4>
+__global__ __launch_bounds__(kBlock) void row_any_nonzero_kernel(const float* __restrict__ x, int64_t n_rows, int d,
+                                                                 int lpr_log2, uint8_t* __restrict__ flags) {
+    const int lpr = 1 << lpr_log2;
+    const int lane = threadIdx.x & 63, l = lane & (lpr - 1), g0 = lane & ~(lpr - 1);
+    const int rows_per_block = kBlock >> lpr_log2;
+    const int64_t stride = (int64_t)gridDim.x * rows_per_block * kUnroll;
+    const int64_t first = (int64_t)blockIdx.x * rows_per_block * kUnroll;
+    const uint64_t gmask = lpr == 64 ? ~0ull : ((1ull << lpr) - 1);
+    for (int64_t base = first; base < n_rows; base += stride) {          // block-uniform bound
+        bool nz[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t r = base + (int64_t)u * rows_per_block + (threadIdx.x >> lpr_log2);
+            nz[u] = false;
+            if (r < n_rows) {
+                if (VEC4) {
+                    const float4* row = reinterpret_cast<const float4*>(x + r * d);
+                    for (int c = l; c < d / 4; c += lpr) {
+                        const float4 v = row[c];
+                        nz[u] |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+                    }
+                } else {
+                    for (int c = l; c < d; c += lpr) nz[u] |= x[r * d + c] != 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const uint64_t b = __ballot(nz[u]);
+            const int64_t r = base + (int64_t)u * rows_per_block + (threadIdx.x >> lpr_log2);
+            if (l == 0 && r < n_rows) flags[r] = ((b >> g0) & gmask) != 0 ? 1 : 0;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int hmx_gather_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n,
@@ -143,6 +182,24 @@ extern "C" int hmx_gather_rows_f32(const float* table, int64_t n_rows, int64_t d
     if (n < 0 || d <= 0 || n_rows <= 0) return HMX_EINVAL;
     if (n > 0 && (!table || !ids || !out)) return HMX_EINVAL;
     return launch_gather<false>(table, n_rows, nullptr, 0, d, ids, nullptr, n, out, (hipStream_t)stream);
+}
+
+extern "C" int hmx_row_any_nonzero_f32(const float* x, int64_t n_rows, int64_t d, uint8_t* flags, void* stream) {
+    HMX_ENTER();
+    if (n_rows < 0 || d <= 0 || d >= ((int64_t)1 << 31)) return HMX_EINVAL;
+    if (n_rows == 0) return HMX_OK;
+    if (!x || !flags) return HMX_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = d % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    const int l2 = lpr_log2_for(vec ? d / 4 : d);
+    const int64_t rows_per_block = (kBlock >> l2) * kUnroll;
+    const int grid = (int)std::min<int64_t>(hmx_ceil_div(n_rows, rows_per_block), kMaxGrid);
+    void* span = hmx_profile_begin("row_any_nonzero", s);
+    if (vec) hipLaunchKernelGGL(row_any_nonzero_kernel<true>, dim3(grid), dim3(kBlock), 0, s, x, n_rows, (int)d, l2, flags);
+    else hipLaunchKernelGGL(row_any_nonzero_kernel<false>, dim3(grid), dim3(kBlock), 0, s, x, n_rows, (int)d, l2, flags);
+    hmx_profile_end(span, s);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
 }
 
 extern "C" int hmx_gather_rows_bf16(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n,

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "hmx_error_string": (c_char_p, [c_int]),
     "hmx_gather_rows_f32": (c_int, [P, I64, I64, P, I64, P, P]),
     "hmx_gather_rows_bf16": (c_int, [P, I64, I64, P, I64, P, P]),
+    "hmx_row_any_nonzero_f32": (c_int, [P, I64, I64, P, P]),
     "hmx_gather_routed_f32": (c_int, [P, I64, P, I64, I64, P, P, I64, P, P]),
     "hmx_gather_gelu_rows_f32": (c_int, [P, I64, I64, P, I64, P, P]),
     "hmx_scatter_add_rows_workspace_bytes": (c_size_t, [I64, I64, I64]),

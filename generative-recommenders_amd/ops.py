@@ -343,6 +343,17 @@ def score_topk(queries, prepared, k, exclude=None, id_offset=0, return_stats=Fal
     return ids, sc
 
 
+def touched_rows(x):
+    """Ascending indices (int64) of the rows of x (n_rows, d) that hold a non-zero value: one pass over x on the HIP
+    kernel, then a compaction of the per-row flags (host sync: the count)."""
+    _need_cuda(x)
+    x = _f32c(x)
+    flags = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+    hmx.check(hmx.lib().hmx_row_any_nonzero_f32(hmx.ptr(x), x.shape[0], x.shape[1], hmx.ptr(flags),
+                                                hmx.current_stream()), "hmx_row_any_nonzero_f32")
+    return flags.nonzero().flatten()
+
+
 def sample_thresholds(queries, prepared, k, n_ranges=1, n_values=1):
     """(n_q,) start thresholds the bf16 pass samples from this table (-inf for launch shapes that do not sample):
     at least k sampled rows of the table score that much.  Exchanged between item-range shards (retrieval.py);

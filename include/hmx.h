@@ -45,6 +45,11 @@ const char* hmx_error_string(int code);
 int hmx_gather_rows_f32(const float* table, int64_t n_rows, int64_t d, const int64_t* ids, int64_t n, float* out,
                         void* stream);
 
+/* flags[r] = 1 when row r of x (n_rows, d) holds any value != 0 (NaN counts as non-zero), else 0.  The
+ * data-parallel train step uses it on the dense table gradients (embedding.py:436-454 backward) to find the rows a
+ * rank touched, so that only those rows are exchanged; no counterpart in the single-process reference. */
+int hmx_row_any_nonzero_f32(const float* x, int64_t n_rows, int64_t d, uint8_t* flags, void* stream);
+
 /* The same gather with the copy rounded to bf16 (round to nearest even) as it is written: out[i, :] =
  * bf16(table[ids[i], :]), for consumers that feed the rows to a bf16 MFMA product anyway (scoring tables, the
  * single-bf16 projection mode).  The write stream is half as wide.  d % 4 == 0; no backward (use the f32 form under
