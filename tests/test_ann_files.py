@@ -100,6 +100,28 @@ def test_retrieve_files_on_gpu_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_retrieve_files_on_gpu_large_ids_and_fewer_candidates_than_k(tmp_path):
+    """uint64 ids above 2^63 survive the device-side row -> id mapping bit for bit, and with fewer candidates than k
+    the tail repeats the last valid id (the reader has no "missing" value)."""
+    from oracle import c_oracle as C
+    rng = np.random.default_rng(5)
+    table = rng.standard_normal((7, 32)).astype(np.float32)
+    ids = (np.uint64(2 ** 63) + rng.permutation(7).astype(np.uint64) * np.uint64(3)).astype(np.uint64)
+    ids[0] = np.uint64(2 ** 64 - 1)
+    queries = rng.standard_normal((40, 32)).astype(np.float32)
+    A.save_emb(table, tmp_path / "embedding.fbin")
+    A.save_emb(ids.reshape(-1, 1), tmp_path / "id.u64bin")
+    A.save_emb(queries, tmp_path / "query.fbin")
+    rows = A.retrieve_files(tmp_path / "embedding.fbin", tmp_path / "id.u64bin", tmp_path / "query.fbin",
+                            tmp_path / "id100.u64bin", query_ann_top_k=10)
+    got = A.read_result_ids(tmp_path / "id100.u64bin")
+    want_rows, _ = C.score_topk(queries, table, 7)
+    want_rows = np.concatenate([want_rows, np.repeat(want_rows[:, -1:], 3, axis=1)], axis=1)
+    assert got.dtype == np.uint64 and got.shape == (40, 10)
+    assert np.array_equal(rows, want_rows) and np.array_equal(got, ids[want_rows])
+
+
+@pytest.mark.gpu
 def test_candidate_table_generation_matches_reference_golden(tmp_path):
     """SharedEmbeddingModule.get_item_embeddings / save_item_embeddings / get_complete_embeddings on the fused
     gather+GELU kernel against outputs captured from the reference (embedding.py:613-735, ids-only)."""
