@@ -32,6 +32,35 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
             dist.broadcast(t.data, src=src, group=group)
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def _host_staged(group, t) -> bool:
+    """gloo with GPU tensors (tests and rehearsals with several ranks on one GPU): collectives go through host copies
+    and finish before returning; gloo's own handling of GPU tensors was seen to lock up now and then there."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_flat(out, t, group, async_op=False):
+    if _host_staged(group, t):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, t.cpu(), group=group)
+        out.copy_(host)
+        return _Done()
+    return dist.all_gather_into_tensor(out, t, group=group, async_op=async_op)
+
+
+def _all_reduce_sum(t, group, async_op=False):
+    if _host_staged(group, t):
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
 def _hip_row_ops():
     from . import ops
     return (lambda table, ids: ops.gather_rows(table, ids),
@@ -86,7 +115,7 @@ class GradientSync:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         for p in dense_big:
-            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            works.append(_all_reduce_sum(p.grad, self.group, async_op=True))
         pending_sparse = [self._sparse_begin(p, scale) for p in sparse]
         flat = self._bucket()
         if flat is not None:
@@ -94,7 +123,7 @@ class GradientSync:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             torch._foreach_copy_(self._views, [p.grad for p in self.small])
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            works.append(_all_reduce_sum(flat, self.group, async_op=True))
         for w in works:
             w.wait()
         if flat is not None:
@@ -123,7 +152,7 @@ class GradientSync:
         ids = row_ops[2](g) if len(row_ops) > 2 else (g != 0).any(dim=1).nonzero().flatten()
         counts = torch.tensor([ids.numel()], dtype=torch.int64, device=g.device)
         all_counts = torch.empty(self.world, dtype=torch.int64, device=g.device)
-        dist.all_gather_into_tensor(all_counts, counts, group=self.group)
+        _all_gather_flat(all_counts, counts, self.group)
         n_max = int(all_counts.max().item())
         pad_ids = torch.full((max(n_max, 1),), -1, dtype=torch.int64, device=g.device)
         pad_rows = torch.zeros(max(n_max, 1), g.shape[1], dtype=g.dtype, device=g.device)
@@ -134,8 +163,8 @@ class GradientSync:
                 pad_rows.mul_(scale)             # each rank scales what it sends: 1 / world of the gathered volume
         out_ids = torch.empty(self.world * pad_ids.numel(), dtype=torch.int64, device=g.device)
         out_rows = torch.empty(self.world * pad_rows.shape[0], g.shape[1], dtype=g.dtype, device=g.device)
-        w1 = dist.all_gather_into_tensor(out_ids, pad_ids, group=self.group, async_op=True)
-        w2 = dist.all_gather_into_tensor(out_rows, pad_rows, group=self.group, async_op=True)
+        w1 = _all_gather_flat(out_ids, pad_ids, self.group, async_op=True)
+        w2 = _all_gather_flat(out_rows, pad_rows, self.group, async_op=True)
         self.last_stats[id(p)] = {"rows_sent": int(ids.numel()), "rows_padded": int(pad_ids.numel())}
         return p, ids, out_ids, out_rows, (w1, w2)
 

@@ -125,20 +125,19 @@ class ShardedRetriever:
 
     def _all_gather(self, t):
         """(n, k) per rank -> (world, n, k); one collective.  RCCL: launched asynchronously on its own stream, wait()
-        orders the current stream behind it.  gloo (CPU tests, and rehearsals with several ranks on one GPU): run to
-        completion here -- its asynchronous form on GPU tensors works from helper threads that synchronise streams,
-        and with further launches and allocations queued behind it on the main thread that was seen to lock up."""
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        blocking = dist.get_backend(self.group) == "gloo" and t.is_cuda
-        if blocking:
-            torch.cuda.synchronize(t.device)
+        orders the current stream behind it.  gloo with GPU tensors (tests and rehearsals with several ranks on one
+        GPU): the tensor is copied to the host, gathered there and copied back, all before returning -- gloo's own
+        handling of GPU tensors (helper threads that copy and synchronise streams) was seen to lock up now and then
+        with two processes on one GPU, asynchronous or not."""
+        staged = dist.get_backend(self.group) == "gloo" and t.is_cuda
+        src = t.cpu() if staged else t
+        out = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
         try:
-            w = dist.all_gather_into_tensor(out, t, group=self.group, async_op=not blocking)
+            w = dist.all_gather_into_tensor(out, src, group=self.group, async_op=not staged)
         except (RuntimeError, NotImplementedError):      # backend without the flat form
-            w = dist.all_gather(list(out.unbind(0)), t, group=self.group, async_op=not blocking)
-        if blocking:
-            torch.cuda.synchronize(t.device)
-            return out, self._Done()
+            w = dist.all_gather(list(out.unbind(0)), src, group=self.group, async_op=not staged)
+        if staged:
+            return out.to(t.device), self._Done()
         return out, w
 
     def search(self, queries, k):

@@ -131,6 +131,9 @@ class _FakeDist:
     def get_world_size(self, group=None):
         return self.grid.world
 
+    def get_backend(self, group=None):
+        return "threads"
+
     def all_gather_into_tensor(self, out, t, group=None, async_op=False):
         got, done = self.grid.gather(self.local.rank, t)
         out.copy_(got.reshape(out.shape))
