@@ -83,7 +83,8 @@ def barrier_sync(world):
 def max_over_ranks(x, world):
     if world == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    # RCCL reduces device tensors; under gloo (rehearsals) the number stays on the host
+    t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

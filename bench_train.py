@@ -126,7 +126,7 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     _sync(world)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     spans = {tag: hmx.profile_collect(tag) for tag in TAGS}

@@ -29,7 +29,12 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
     """Make every rank start from rank `src`'s parameters and buffers."""
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            if _host_staged(group, t):
+                host = t.data.cpu()
+                dist.broadcast(host, src=src, group=group)
+                t.data.copy_(host)
+            else:
+                dist.broadcast(t.data, src=src, group=group)
 
 
 class _Done:
