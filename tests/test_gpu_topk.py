@@ -317,3 +317,23 @@ def test_launches_between_the_plan_switch_points(nq, rows, d, k):
     want_ids, want_sc = ops.score_topk_exact(qq, tq, k)
     assert torch.equal(ids, want_ids) and torch.equal(sc, want_sc)
     _check(ids[:24], sc[:24], q[:24], t, k)
+
+
+@pytest.mark.parametrize("nq,sampled", [(213_568, True), (262_144, True), (100_000, True), (65_536, True), (40_000, False),
+                                        (4096, False)])
+def test_which_launch_shapes_sample_their_start(nq, sampled):
+    """Launches of one to four item splits (512 query tiles or more) have sampled start thresholds to exchange between
+    item ranges -- the ragged last launch of a 1 M-query search (213,568 queries) among them; launches of more splits
+    report -inf (they are seeded from table prefixes instead)."""
+    g = torch.Generator().manual_seed(nq)
+    t = torch.randn(40_000, 64, generator=g).to(DEV)
+    q = torch.randn(nq, 64, generator=g).to(DEV)
+    prep = ops.PreparedTable(t)
+    thr = ops.sample_thresholds(q, prep, 10, n_ranges=2)
+    vals = ops.sample_thresholds(q, prep, 10, n_ranges=2, n_values=4)
+    if sampled:
+        assert bool(torch.isfinite(thr).all()) and bool(torch.isfinite(vals).all())
+        exact = ops.score_topk_exact(q[:256], t, 10)[1]
+        assert bool((thr[:256] <= exact[:, 9]).all())          # ten rows of the table do score that much
+    else:
+        assert bool(torch.isinf(thr).all()) and bool((thr < 0).all()) and bool(torch.isinf(vals).all())
