@@ -636,13 +636,53 @@ class _ProjScan(torch.autograd.Function):
                 None, None, None, *dws)
 
 
+def _scan_width(ED):
+    """The scan kernels group a head's channels in powers of two (>= 32)."""
+    p = 32
+    while p < ED:
+        p *= 2
+    return p
+
+
+def _pad_channels(t, H, ED, EDp, channel_dim):
+    """An axis of H * ED channels (head-major) widened to H * EDp with zeros (differentiable)."""
+    F = torch.nn.functional
+    if channel_dim == 0:                                   # (H * ED, ...) parameters
+        rest = t.shape[1:]
+        pad = (0, 0) * len(rest) + (0, EDp - ED)
+        return F.pad(t.reshape(H, ED, *rest), pad).reshape(H * EDp, *rest)
+    T = t.shape[0]                                         # (T, H * ED) activations
+    return F.pad(t.reshape(T, H, ED), (0, EDp - ED)).reshape(T, H * EDp)
+
+
+def _padded_scan(xc, z, Wdt, bdt, A_log, D, L, ED, H, dbc=None, Wdbc=None):
+    """Inner widths that are not a power of two (the reference's default hidden size 60 gives 120): the head's channels
+    are widened with zero channels -- zero input, zero gate, zero parameters, so they stay zero and add nothing to the
+    shared B / C / dt gradients -- and the result is cut back.  Same values as the unpadded recurrence."""
+    EDp = _scan_width(ED)
+    T = xc.shape[0]
+    xcp = _pad_channels(xc, H, ED, EDp, 1)
+    zp = _pad_channels(z, H, ED, EDp, 1) if z is not None else None
+    Wdt, bdt, A_log, D = (_pad_channels(t, H, ED, EDp, 0) for t in (Wdt, bdt, A_log, D))
+    if Wdbc is not None:
+        Wp = [torch.nn.functional.pad(w, (0, EDp - ED)) for w in Wdbc]
+        y = _ProjScan.apply(xcp, zp, Wdt, bdt, A_log, D, L, EDp, H, *Wp)
+    else:
+        y = _Scan.apply(xcp, zp, dbc, Wdt, bdt, A_log, D, L, EDp, H)
+    return y.reshape(T, H, EDp)[..., :ED].reshape(T, H * ED)
+
+
 def proj_scan_gated(xc, z, Wdbc, Wdt, bdt, A_log, D, L, ED, H):
     """selective_scan_gated(xc, z, heads_linear(xc, Wdbc), ...): Wdbc is one (48, ED) deltaBC weight per head."""
+    if ED != _scan_width(ED):
+        return _padded_scan(xc, z, Wdt, bdt, A_log, D, L, ED, H, Wdbc=Wdbc)
     return _ProjScan.apply(xc, z, Wdt, bdt, A_log, D, L, ED, H, *Wdbc)
 
 
 def selective_scan_gated(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H):
     """(scan(xc; dbc, params) + D xc) * SiLU(z) for all heads (z = None: no gate); see hmx_scan_fwd."""
+    if ED != _scan_width(ED):
+        return _padded_scan(xc, z, Wdt, bdt, A_log, D, L, ED, H, dbc=dbc)
     return _Scan.apply(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H)
 
 

@@ -585,3 +585,58 @@ def test_rerank_candidates_and_auxiliary_losses():
     G.assert_close(loss.compute_diversity_loss(u.to(DEV)).cpu(), ((un @ un.t()) * (1 - torch.eye(5))).abs().mean(), 1e-5, 1e-6)
     ids = H.HardNegativeMiner(None, table.to(DEV), top_k=4).mine_hard_negatives_popular(u.to(DEV), torch.arange(10.0).to(DEV))
     assert ids.shape == (5, 4) and int(ids.min()) >= 0 and int(ids.max()) < 10
+
+
+def test_log2feats_and_grads_vs_oracle_reference_default_width():
+    """d = 60 (the reference's default hidden size: head_dim 30, inner width 120, neither a power of two), L = 20,
+    B = 4 with ragged left padding; eval mode.  Forward and every parameter gradient against the CPU oracle."""
+    from generative_recommenders_amd import synth
+    U, I, d, L, B = 200, 900, 60, 20, 4
+    ref = O.build_model(U, I, d=d, L=L, seed=31).eval()
+    m = H.Hydra(U, I, {}, H.IDS_ONLY_FEAT_TYPES, H.make_args(d, L),
+                H.SharedEmbeddingModule(U, I, {}, H.IDS_ONLY_FEAT_TYPES, H.make_args(d, L)))
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m.to(DEV).eval()
+    bt = synth.train_batch(B, L, U, I, "cpu", seed=32, pad_frac=0.5)
+    feat = [[] for _ in range(B)]
+    want = ref.log2feats(bt["seq"], feat, bt["tok"], bt["ts"], bt["act"], bt["dwell"])
+    got = m.log2feats(bt["seq"].to(DEV), feat, bt["tok"].to(DEV), bt["ts"].to(DEV), bt["act"].to(DEV), bt["dwell"].to(DEV))
+    close(got, want, 2e-3, 1e-3, "log2feats d60")
+    g = torch.randn_like(want)
+    want.backward(g)
+    got.backward(g.to(DEV))
+    pr, pd = dict(ref.named_parameters()), dict(m.named_parameters())
+    checked = 0
+    for k, q in pr.items():
+        if q.grad is None:
+            assert pd[k].grad is None or float(pd[k].grad.abs().sum()) == 0.0, k
+            continue
+        close(pd[k].grad, q.grad, 8e-3, 6.5e-3, "grad " + k)
+        checked += 1
+    assert checked > 100
+
+
+def test_train_step_runs_at_the_reference_default_width():
+    """A whole train step (encoder, top-50 miner, fused InfoNCE, backward) at d = 60: same distribution of draws as
+    the oracle's step on the same batch and weights, so the loss stays close; every gradient is finite and the
+    padding rows of both tables receive none."""
+    from generative_recommenders_amd import synth
+    U, I, d, L, B = 200, 3000, 60, 20, 16
+    ref = O.build_model(U, I, d=d, L=L, dropout=0.0, seed=41).train()
+    m = H.build_model(U, I, d=d, L=L, dropout=0.0, device=DEV, seed=41).train()
+    m.load_state_dict(ref.state_dict(), strict=True)
+    bt = synth.train_batch(B, L, U, I, "cpu", seed=42)
+    feat = [[] for _ in range(B)]
+    torch.manual_seed(0)
+    want = ref(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"], bt["act"],
+               bt["dwell"])
+    torch.manual_seed(0)
+    loss = m(*(bt[k].to(DEV) for k in ("seq", "pos", "neg", "tok", "next_tok")), None, feat, feat, feat,
+             *(bt[k].to(DEV) for k in ("ts", "act", "dwell")))
+    loss.backward()
+    assert abs(loss.item() - want.item()) < 0.15 * abs(want.item()) + 0.05, (loss.item(), want.item())
+    for k, q in m.named_parameters():
+        if q.grad is not None:
+            assert bool(torch.isfinite(q.grad).all()), k
+    se = m.shared_embeddings
+    assert float(se.item_emb.weight.grad[0].abs().sum()) == 0.0 and float(se.user_emb.weight.grad[0].abs().sum()) == 0.0
