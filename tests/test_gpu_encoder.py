@@ -640,3 +640,35 @@ def test_train_step_runs_at_the_reference_default_width():
             assert bool(torch.isfinite(q.grad).all()), k
     se = m.shared_embeddings
     assert float(se.item_emb.weight.grad[0].abs().sum()) == 0.0 and float(se.user_emb.weight.grad[0].abs().sum()) == 0.0
+
+
+def test_training_loop_gradient_modes_at_the_reference_default_width():
+    """The two opt-in gradient modes of the training loop at d = 60 (padded scan channels, unfused block path): same
+    loss, same gradients as autograd accumulation on the same draws (same torch seed)."""
+    from generative_recommenders_amd import ops, synth
+    U, I, d, L, B = 200, 3000, 60, 20, 16
+    bt = synth.train_batch(B, L, U, I, DEV, seed=52)
+    feat = [[] for _ in range(B)]
+    grads, losses = [], []
+    try:
+        for direct in (False, True):
+            E.set_direct_param_grad(direct)
+            ops.set_fused_table_grad(direct)
+            m = H.build_model(U, I, d=d, L=L, dropout=0.0, device=DEV, seed=51).train()
+            torch.manual_seed(7)
+            loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"],
+                     bt["act"], bt["dwell"])
+            loss.backward()
+            losses.append(loss.item())
+            grads.append({k: (None if q.grad is None else q.grad.clone()) for k, q in m.named_parameters()})
+    finally:
+        E.set_direct_param_grad(False)
+        ops.set_fused_table_grad(False)
+    assert losses[0] == losses[1]
+    assert grads[0].keys() == grads[1].keys()
+    for k in grads[0]:
+        a, c = grads[0][k], grads[1][k]
+        zero = lambda t: t is None or float(t.abs().sum()) == 0.0      # noqa: E731 - a gradient that is absent or all zero
+        assert (a is None) == (c is None) or (zero(a) and zero(c)), k
+        if a is not None and c is not None:
+            close(c, a, 2e-5, 2e-5, "direct grad " + k)
