@@ -207,13 +207,32 @@ class MultiScaleUserEncoder(nn.Module):
 
 
 class PositionAwareEncoder(nn.Module):
-    """hydra3.py:1044-1082: constructed by Hydra but never called; its parameters exist for state_dict parity."""
+    """hydra3.py:1044-1082: constructed by Hydra (its parameters are part of the state_dict) but not called by the
+    model; the forward is the reference's, on the HIP kernels."""
 
     def __init__(self, hidden_dim, max_len=512):
         super().__init__()
         self.hidden_dim, self.max_len = hidden_dim, max_len
         self.position_weights = nn.Parameter(torch.ones(max_len))
         self.position_attention = nn.MultiheadAttention(hidden_dim, 2, dropout=0.2, batch_first=True)
+
+    def forward(self, sequence, positions=None):
+        """sequence (B, L, d) -> sequence + self-attention over the sequence scaled per position by
+        softmax(position_weights[:L]) (hydra3.py:1065-1082; `positions` is unused there as well)."""
+        B, L, d = sequence.shape
+        x2 = sequence.reshape(B * L, d)
+        w = torch.softmax(self.position_weights[:L], dim=0)                    # L numbers
+        xw = E.mul_scale(x2, w.repeat(B).unsqueeze(1).expand(B * L, d).contiguous(), 1.0)
+        mha = self.position_attention
+        W, bias = mha.in_proj_weight, mha.in_proj_bias
+        q = E.linear(xw, W[:d], bias[:d])
+        kv = E.linear(xw, W[d:], bias[d:])
+        drop = None
+        if self.training and mha.dropout > 0.0:
+            drop = feature_ops.dropout_multiplier((B, mha.num_heads, L, L), mha.dropout, sequence.device)
+        att = feature_ops.attention(q, kv, drop, B, L, L, mha.num_heads)
+        out = E.linear(att, mha.out_proj.weight, mha.out_proj.bias, r1=x2, c1=1.0)
+        return out.view(B, L, d)
 
 
 class AdaptiveHardNegativeSampler(nn.Module):
@@ -491,6 +510,12 @@ class Hydra(nn.Module):
         B, C = candidate_ids.shape
         rows = self._project_small(self.shared_embeddings.item_emb(candidate_ids.reshape(B * C)))
         return torch.bmm(user.unsqueeze(1), rows.view(B, C, -1).transpose(1, 2)).squeeze(1)
+
+    def save_item_emb(self, item_ids, retrieval_ids, feat_dict, save_path, batch_size=1024):
+        """hydra3.py:730-761 (embedding.fbin + id.u64bin of the candidate items).  The reference's body calls a
+        `feat2emb` that its Hydra does not have; the files it describes are what the shared module's
+        save_item_embeddings (embedding.py:654-684) writes, so the call goes there."""
+        return self.shared_embeddings.save_item_embeddings(item_ids, retrieval_ids, feat_dict, save_path, batch_size)
 
     def prepared_item_table(self, refresh=True):
         """bf16 scoring copy of the item table (rebuilt after every optimizer step while training)."""

@@ -672,3 +672,30 @@ def test_training_loop_gradient_modes_at_the_reference_default_width():
         assert (a is None) == (c is None) or (zero(a) and zero(c)), k
         if a is not None and c is not None:
             close(c, a, 2e-5, 2e-5, "direct grad " + k)
+
+
+@pytest.mark.parametrize("B,L,d", [(3, 17, 32), (2, 51, 60)])
+def test_position_aware_encoder_matches_the_reference_formula(B, L, d):
+    """hydra3.py:1065-1082 on the HIP kernels against the same module evaluated with torch's own attention (eval
+    mode), forward and all gradients."""
+    torch.manual_seed(B + L)
+    m = H.PositionAwareEncoder(d, max_len=L + 5)
+    with torch.no_grad():
+        m.position_weights.copy_(torch.randn(L + 5))
+    ref = H.PositionAwareEncoder(d, max_len=L + 5)
+    ref.load_state_dict(m.state_dict())
+    ref.eval()
+    m.to(DEV).eval()
+    x = torch.randn(B, L, d)
+    xr = x.clone().requires_grad_()
+    ws = xr * torch.softmax(ref.position_weights[:L], dim=0).view(1, -1, 1)
+    want = xr + ref.position_attention(ws, ws, ws)[0]
+    xd = x.to(DEV).requires_grad_()
+    got = m(xd, None)
+    close(got, want, 2e-3, 1e-3, "position-aware encoder")
+    g = torch.randn_like(want)
+    want.backward(g)
+    got.backward(g.to(DEV))
+    close(xd.grad, xr.grad, 4e-3, 2.5e-3, "dx")
+    for (k, a), (_, r) in zip(m.named_parameters(), ref.named_parameters()):
+        close(a.grad, r.grad, 8e-3, 6.5e-3, "grad " + k)
