@@ -139,7 +139,8 @@ def test_candidate_table_generation_matches_reference_golden(tmp_path):
     seq = G.t(s, "G11/seq").cuda()
     G.assert_close(se.get_complete_embeddings(seq, None, fusion_style="late").cpu(), G.t(s, "G11/late"), 2e-6, 2e-7, "late")
     G.assert_close(se.get_complete_embeddings(seq, None, fusion_style="early").cpu(), G.t(s, "G11/early"), 0, 0, "early")
-    se.save_item_embeddings(G.t(s, "G11/item_ids").tolist(), G.t(s, "G11/retrieval_ids").tolist(), {}, tmp_path)
+    # through the model-level hook that infer.py:328 calls (it forwards to the shared module's writer)
+    m.save_item_emb(G.t(s, "G11/item_ids").tolist(), G.t(s, "G11/retrieval_ids").tolist(), {}, tmp_path)
     G.assert_close(torch.from_numpy(A.load_fbin(tmp_path / "embedding.fbin")), G.t(s, "G11/saved/embedding.fbin"),
                    2e-6, 2e-7, "embedding.fbin")
     assert np.array_equal(A.load_u64bin(tmp_path / "id.u64bin"), s["G11/saved/id.u64bin"].reshape(-1))
