@@ -549,7 +549,8 @@ class Hydra(nn.Module):
         self.last_mined_ids = hard
         hard = hard.unsqueeze(1).expand(-1, log_feats.shape[1], -1)
         return self.enchanced_loss(user_embs=log_feats, pos_embs=pos_embs, neg_embs=neg_embs, hard_negatives=hard,
-                                   loss_mask=(next_mask == 1), item_table=item_table, predrawn=predrawn)
+                                   loss_mask=(next_mask == 1).to(log_feats.device), item_table=item_table,
+                                   predrawn=predrawn)     # main.py leaves next_mask on the host (hydra3.py:688)
 
 
 IDS_ONLY_FEAT_TYPES = {k: [] for k in ('user_sparse', 'item_sparse', 'user_array', 'item_array',

@@ -8,6 +8,8 @@ for forward values, 2x that for input gradients and 4x / 6.5x for parameter grad
 Fast mode (one bf16 MFMA per product, operands rounded to 8 significant bits) is asserted at 3e-2 / 1e-2 on the
 end-to-end encoder output (test_fast_bf16_mode_tolerance); its parameter gradients are bf16-noisy (up to 13 % rms
 on the deltaBC projection at L = 100) and are not asserted."""
+import math
+
 import pytest
 import torch
 
@@ -699,3 +701,40 @@ def test_position_aware_encoder_matches_the_reference_formula(B, L, d):
     close(xd.grad, xr.grad, 4e-3, 2.5e-3, "dx")
     for (k, a), (_, r) in zip(m.named_parameters(), ref.named_parameters()):
         close(a.grad, r.grad, 8e-3, 6.5e-3, "grad " + k)
+
+
+def test_training_loop_exactly_as_the_reference_script_drives_it():
+    """main.py:672-715 verbatim around the drop-in model: next_token_type stays on the host, the forward runs under
+    torch.amp.autocast("cuda"), the loss goes through a GradScaler, then clip_grad_norm_, AdamW and the scheduler
+    step.  Two steps must run, give finite losses and change the parameters; padding rows stay zero-gradient."""
+    from generative_recommenders_amd import synth
+    U, I, d, L, B = 200, 3000, 64, 30, 8
+    model = H.build_model(U, I, d=d, L=L, dropout=0.2, device=DEV, seed=61).train()
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.98), weight_decay=0.1)
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda step: 1.0)
+    scaler = torch.amp.GradScaler('cuda')
+    before = {k: q.detach().clone() for k, q in model.named_parameters()}
+    losses = []
+    for step in range(2):
+        bt = synth.train_batch(B, L, U, I, "cpu", seed=70 + step)
+        seq, pos, neg, token_type, ts, action_type, dwell_bins = (bt[k].to(DEV) for k in
+                                                                  ("seq", "pos", "neg", "tok", "ts", "act", "dwell"))
+        next_token_type, next_action_type = bt["next_tok"], None            # never moved to the device by main.py
+        feat = [[] for _ in range(B)]
+        optimizer.zero_grad()
+        with torch.amp.autocast("cuda"):
+            loss = model(seq, pos, neg, token_type, next_token_type, next_action_type, feat, feat, feat, ts, action_type,
+                         dwell_bins)
+        losses.append(loss.item())
+        scaler.scale(loss).backward()
+        scaler.unscale_(optimizer)
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1)
+        assert bool(torch.isfinite(norm))
+        assert float(model.shared_embeddings.item_emb.weight.grad[0].abs().sum()) == 0.0
+        scaler.step(optimizer)
+        scaler.update()
+        if optimizer.state:
+            scheduler.step()
+    assert all(math.isfinite(l) for l in losses), losses
+    moved = sum(int(not torch.equal(before[k], q.detach())) for k, q in model.named_parameters())
+    assert moved > 100, moved
