@@ -201,3 +201,60 @@ def test_gradient_sync_on_a_rank_grid_in_one_process(world, monkeypatch):
     assert torch.equal(results[0]["sparse"][1], results[0]["dense"][1])
     touched = torch.cat(id_sets).unique()
     assert int((results[0]["sparse"][0].abs().sum(1) > 0).sum()) == touched.numel()
+
+
+def test_data_parallel_train_step_equals_the_average_of_the_ranks_own_steps(monkeypatch):
+    """Two ranks (threads) run Hydra's train step on their own batches and meet in GradientSync: every rank must end
+    with the mean of the gradients that the two batches give on their own (each rank draws its negatives from its own
+    batch, as one process of the reference does), tables included."""
+    from generative_recommenders_amd import hydra as H
+    from generative_recommenders_amd import parallel, synth
+    world, U, I, d, L, B = 2, 300, 5000, 64, 20, 6
+    batches = [synth.train_batch(B, L, U, I, "cuda", seed=90 + r) for r in range(world)]
+    feat = [[] for _ in range(B)]
+
+    def step(model, bt, seed):
+        torch.manual_seed(seed)                                  # the step's draws (negatives) follow this seed
+        loss = model(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"],
+                     bt["act"], bt["dwell"])
+        loss.backward()
+        return {k: q.grad.clone() for k, q in model.named_parameters() if q.grad is not None}
+
+    alone = [step(H.build_model(U, I, d=d, L=L, dropout=0.0, device="cuda", seed=5).train(), batches[r], 100 + r)
+             for r in range(world)]
+    grid = _Grid(world)
+    fake = _FakeDist(grid)
+    monkeypatch.setattr(parallel, "dist", fake)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        grid.turn.acquire()
+        fake.local.rank = rank
+        try:
+            model = H.build_model(U, I, d=d, L=L, dropout=0.0, device="cuda", seed=5).train()
+            grads = step(model, batches[rank], 100 + rank)
+            del grads
+            parallel.GradientSync(model, big_bytes=1 << 18)()    # both tables take the sparse row exchange
+            results[rank] = {k: q.grad.clone() for k, q in model.named_parameters() if q.grad is not None}
+        except BaseException as e:                               # noqa: BLE001 - reported by the main thread
+            errors.append((rank, repr(e)))
+            grid.barrier.abort()
+        finally:
+            grid.turn.release()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    keys = set(alone[0]) | set(alone[1])
+    # parameters that no step reaches (a module the model never calls) take part in the exchange as zeros
+    assert set(results[0]) == set(results[1]) and keys <= set(results[0])
+    for k in set(results[0]) - keys:
+        assert float(results[0][k].abs().sum()) == 0.0, k
+    for k in keys:
+        assert torch.equal(results[0][k], results[1][k]), k
+        zero = torch.zeros_like(results[0][k])
+        want = (alone[0].get(k, zero) + alone[1].get(k, zero)) * 0.5
+        torch.testing.assert_close(results[0][k], want, rtol=1e-5, atol=1e-7, msg=k)
