@@ -239,7 +239,8 @@ def hydra_block(blk, x2, mask1, L, first):
     drop = None
     pdrop = blk.dropout.p
     if blk.training and pdrop > 0.0:
-        drop = drop_pool.take(T, d, pdrop, x2.device)
+        fixed = blk.fixed_drop_multiplier
+        drop = _f32c(fixed.reshape(T, d)) if fixed is not None else drop_pool.take(T, d, pdrop, x2.device)
     eps = blk.norm1.eps
     x_in, z, y2, rstd1 = _BlockPre.apply(x2, drop, mask1, packed, link, L, H, first, eps, blk.norm1.scale,
                                          mhm.linear_layer1.weight, mhm.linear_layer1.bias,

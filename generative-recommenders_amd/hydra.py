@@ -115,6 +115,9 @@ class MultiHeadMamba(nn.Module):
 
 class _HydraBlockBase(nn.Module):
     first = False
+    # (B, L, d) tensor used in place of a random dropout draw while training (the values nn.Dropout would multiply
+    # by: 0 or 1 / (1 - p)); None = draw.  For repeating a step on recorded multipliers.
+    fixed_drop_multiplier = None
 
     def __init__(self, dim, dt_rank, dim_inner, d_state, args):
         super().__init__()
@@ -136,7 +139,11 @@ class _HydraBlockBase(nn.Module):
         if FUSED_BLOCKS and x2.is_cuda and hmx.SPLIT_BF16 and block_ops.supported(d, len(mhm.mamba)):
             # the block as two fused token-parallel kernels around the conv / scan core
             return block_ops.hydra_block(self, x2.contiguous(), m1, L, self.first).view(B, L, d)
-        n = E.rmsnorm(feature_ops.dropout(x2, self.dropout.p, self.training), self.norm1.scale, self.norm1.eps)
+        if self.training and self.dropout.p > 0.0 and self.fixed_drop_multiplier is not None:
+            xd = E.mul_scale(x2, self.fixed_drop_multiplier.reshape(T, d).contiguous(), 1.0)
+        else:
+            xd = feature_ops.dropout(x2, self.dropout.p, self.training)
+        n = E.rmsnorm(xd, self.norm1.scale, self.norm1.eps)
         p = mhm.mix(n, m1, L)
         # mixer output x_org + W2 p + b2, plus the block's residual: n (first block) or x again (regular block)
         if self.first:

@@ -81,3 +81,26 @@ def assemble_train_draws(store, prefix, loss_mask, num_hard=153, num_inb=359, q_
             hard.append(torch.cat([tiled[s0:e0], fill], dim=1))
     assert di == len(draws)
     return torch.cat(hard), torch.cat(inb)
+
+
+BLOCK_NAMES = ("hydra_first", "hydra.0", "hydra.1", "multi_scale_encoder.short_term_encoder",
+               "multi_scale_encoder.mid_term_encoder", "multi_scale_encoder.long_term_encoder")
+
+
+def block_drop_multipliers(store, prefix):
+    """{block module name: (B, L', d) multiplier} of a train-step fixture recorded with the blocks' dropout on: the
+    reference multiplied each block's input by mask / (1 - p)."""
+    head = prefix + "/dropmask/"
+    p = float(store[prefix + "/p_drop"])
+    return {k[len(head):]: torch.from_numpy(np.array(v)).float() / (1.0 - p) for k, v in store.items() if k.startswith(head)}
+
+
+class FixedDropout(torch.nn.Module):
+    """Stands in for a block's nn.Dropout: multiplies by a given tensor (what nn.Dropout does with its own draw)."""
+
+    def __init__(self, mult):
+        super().__init__()
+        self.mult = mult
+
+    def forward(self, x):
+        return x * self.mult

@@ -274,53 +274,102 @@ def g9_topk(store):
         min_gap50=gap50, min_gap10=gap10, seed=seed)
 
 
+def train_step_case(store, prefix, m, bt, B, put_model=True, block_dropout=None):
+    """One Hydra.forward + backward of the reference model `m` (train mode) on batch `bt`; records the loss, every
+    gradient, the reference's own torch.randint outputs and its mined ids (data, in call order: torch.randint is
+    wrapped for the duration of the forward pass, which does not touch the generator's stream).
+    block_dropout = p: every HydraBlock's nn.Dropout is replaced for this call by a module that multiplies by a
+    recorded multiplier tensor (Bernoulli(1 - p) / (1 - p), exactly what nn.Dropout applies; drawn from a separate
+    generator) so that the step can be repeated elsewhere on the same multipliers; the attention-weight dropout inside
+    nn.MultiheadAttention cannot be recorded and is switched off for such a case."""
+    feat = [[] for _ in range(B)]
+    draws, mined, masks = [], [], {}
+    real_randint, real_mine = torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity
+
+    def rec_randint(*a_, **k_):
+        out = real_randint(*a_, **k_)
+        draws.append(out.clone())
+        return out
+
+    def rec_mine(self, *a_, **k_):
+        out = real_mine(self, *a_, **k_)
+        mined.append(out.clone())
+        return out
+
+    class RecordedDropout(torch.nn.Module):
+        def __init__(self, p, name, gen):
+            super().__init__()
+            self.p, self.name, self.gen = p, name, gen
+
+        def forward(self, x):
+            mult = (torch.rand(x.shape, generator=self.gen) >= self.p).float() / (1.0 - self.p)
+            masks[self.name] = mult
+            return x * mult
+
+    swapped = []
+    if block_dropout is not None:
+        gen = torch.Generator().manual_seed(77)
+        for name, mod in m.named_modules():
+            if isinstance(getattr(mod, "dropout", None), torch.nn.Dropout) and hasattr(mod, "multiheadMamba"):
+                swapped.append((mod, mod.dropout))
+                mod.dropout = RecordedDropout(block_dropout, name, gen)
+        mha_p, m.multi_scale_encoder.cross_attention.dropout = m.multi_scale_encoder.cross_attention.dropout, 0.0
+    m.zero_grad(set_to_none=True)
+    torch.manual_seed(4242)
+    torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity = rec_randint, rec_mine
+    try:
+        with quiet():
+            loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat,
+                     bt["ts"], bt["act"], bt["dwell"])
+    finally:
+        torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity = real_randint, real_mine
+        for mod, dr in swapped:
+            mod.dropout = dr
+        if block_dropout is not None:
+            m.multi_scale_encoder.cross_attention.dropout = mha_p
+    loss.backward()
+    if put_model:
+        put_params(store, prefix, m)
+    put(store, prefix, loss=loss, rng_seed=4242, mined_ids=mined[0], n_draws=len(draws), **bt)
+    for i, dr in enumerate(draws):
+        store[f"{prefix}/draw{i}"] = dr.numpy()
+    for name, mult in masks.items():
+        store[f"{prefix}/dropmask/{name}"] = (mult != 0).numpy()          # multiplier = mask / (1 - p)
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach()
+        if k.endswith(("item_emb.weight", "user_emb.weight")):
+            rows = g.abs().sum(1).nonzero().flatten()
+            store[f"{prefix}/grad_rows/{k}"] = rows.numpy()
+            store[f"{prefix}/grad_vals/{k}"] = g[rows].numpy()
+            assert float(g[0].abs().sum()) == 0.0
+        else:
+            store[f"{prefix}/grad/{k}"] = g.numpy()
+
+
 def g10_train(store):
     for name, (B, L, U, I) in {"small": (3, 12, 20, 400), "chunky": (8, 60, 30, 500)}.items():
         d = 16
         m, a = build_ref_model(U, I, d, L, 0.0, seed=1000 + B)
         m.train()
         bt = synth_batch(B, L, U, I, pads=(0, 2, L - 3, 5, 0, 0, 1, 7)[:B], seed=1010 + B)
-        feat = [[] for _ in range(B)]
-        # The reference's own random draws and mined ids are recorded on the way (data, in call order): torch.randint
-        # is wrapped for the duration of the forward pass, which does not touch the generator's stream.
-        draws, mined = [], []
-        real_randint, real_mine = torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity
-
-        def rec_randint(*a_, **k_):
-            out = real_randint(*a_, **k_)
-            draws.append(out.clone())
-            return out
-
-        def rec_mine(self, *a_, **k_):
-            out = real_mine(self, *a_, **k_)
-            mined.append(out.clone())
-            return out
-
-        torch.manual_seed(4242)
-        torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity = rec_randint, rec_mine
-        try:
-            with quiet():
-                loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat,
-                         bt["ts"], bt["act"], bt["dwell"])
-        finally:
-            torch.randint, ref.HardNegativeMiner.mine_hard_negatives_similarity = real_randint, real_mine
-        loss.backward()
         prefix = f"G10_train_{name}"
-        put_params(store, prefix, m)
-        put(store, prefix, loss=loss, rng_seed=4242, U=U, I=I, d=d, L=L, mined_ids=mined[0], n_draws=len(draws), **bt)
-        for i, dr in enumerate(draws):
-            store[f"{prefix}/draw{i}"] = dr.numpy()
-        for k, p in m.named_parameters():
-            if p.grad is None:
-                continue
-            g = p.grad.detach()
-            if k.endswith(("item_emb.weight", "user_emb.weight")):
-                rows = g.abs().sum(1).nonzero().flatten()
-                store[f"{prefix}/grad_rows/{k}"] = rows.numpy()
-                store[f"{prefix}/grad_vals/{k}"] = g[rows].numpy()
-                assert float(g[0].abs().sum()) == 0.0
-            else:
-                store[f"{prefix}/grad/{k}"] = g.numpy()
+        train_step_case(store, prefix, m, bt, B)
+        put(store, prefix, U=U, I=I, d=d, L=L)
+
+
+def g14_train_d64(store):
+    """Train steps at d = 64 (head_dim 32, inner width 128: the width of the benchmark model): one model, the same
+    batch, once without dropout and once with the blocks' dropout (p = 0.2) applied through recorded multipliers."""
+    B, L, U, I, d = 4, 24, 30, 600, 64
+    m, a = build_ref_model(U, I, d, L, 0.0, seed=1404)
+    m.train()
+    bt = synth_batch(B, L, U, I, pads=(0, 2, L - 3, 5), seed=1414)
+    train_step_case(store, "G14_train_d64", m, bt, B)
+    put(store, "G14_train_d64", U=U, I=I, d=d, L=L)
+    train_step_case(store, "G14_train_d64_drop", m, bt, B, put_model=False, block_dropout=0.2)
+    put(store, "G14_train_d64_drop", U=U, I=I, d=d, L=L, p_drop=0.2)
 
 
 def g11_item_embs(store):
@@ -493,7 +542,7 @@ def main():
     groups = {"g1_pscan": g1_pscan, "g2_selective_scan": g2_selective_scan, "g3_rmsnorm": g3_rmsnorm,
               "g4_mamba": g4_mamba, "g5_mhm": g5_mhm, "g6_blocks": g6_blocks, "g7_multiscale": g7_multiscale,
               "g9_topk": g9_topk, "g10_train": g10_train, "g11_item_embs": g11_item_embs, "g12_d128": g12_d128,
-              "g13_features": g13_features}
+              "g13_features": g13_features, "g14_train_d64": g14_train_d64}
     for fname, fn in groups.items():
         if only and fname not in only:
             continue

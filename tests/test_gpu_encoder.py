@@ -204,6 +204,109 @@ def test_train_step_against_reference_golden(name):
         assert float(g[0].abs().sum()) == 0.0
 
 
+def _train_step_vs_fixture(s, p, m, what):
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    hard, inb = G.assemble_train_draws(s, p, G.t(s, p + "/next_tok") == 1)
+    loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, feat, feat, feat, b["ts"], b["act"], b["dwell"],
+             predrawn=(hard.to(DEV), inb.to(DEV)))
+    loss.backward()
+    assert torch.equal(m.last_mined_ids.cpu(), G.t(s, p + "/mined_ids"))
+    ref_loss = float(s[p + "/loss"])
+    assert abs(loss.item() - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
+    gold = G.grads(s, p)
+    got = {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
+    tables = {k for k in got if k.endswith(("item_emb.weight", "user_emb.weight"))}
+    assert set(gold) == set(got) - tables, set(gold) ^ (set(got) - tables)
+    for k in gold:
+        close(got[k], gold[k], 8e-3, 6.5e-3, f"{what} grad {k}")
+    for k in tables:
+        rows = G.t(s, f"{p}/grad_rows/{k}")
+        g = got[k].cpu()
+        assert torch.equal(g.abs().sum(1).nonzero().flatten(), rows), k
+        close(g[rows], G.t(s, f"{p}/grad_vals/{k}"), 8e-3, 6.5e-3, f"{what} table grad {k}")
+        assert float(g[0].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("drop", [False, True])
+@pytest.mark.parametrize("direct", [False, True])
+def test_train_step_on_the_fused_block_kernels_against_reference_golden(drop, direct):
+    """The reference's train step at d = 64 -- the width at which every HydraBlock runs on the fused block halves
+    (block.hip), the kernels the benchmark times -- on the reference's recorded draws: loss to 1e-4, every parameter
+    and table gradient at the encoder tolerances.  drop: the blocks' dropout (p = 0.2) is on and uses the
+    multipliers the reference applied (fixture), so the dropout placement inside the fused halves (forward, dx and
+    the first block's residual through the normalised input) is compared value by value.  direct: the training
+    loop's gradient modes (weight gradients by batched launches into .grad, table gradients fused)."""
+    from generative_recommenders_amd import block_ops, ops
+    s, base = G.load("g14_train_d64"), "G14_train_d64"
+    p = base + ("_drop" if drop else "")
+    U, I, d, L = (int(s[f"{base}/{k}"]) for k in "UIdL")
+    assert block_ops.supported(d, 2) and H.FUSED_BLOCKS
+    try:
+        E.set_direct_param_grad(direct)
+        ops.set_fused_table_grad(direct)
+        args = H.make_args(d, L, dropout=0.2 if drop else 0.0)
+        m = H.Hydra(U, I, {}, H.IDS_ONLY_FEAT_TYPES, args, H.SharedEmbeddingModule(U, I, {}, H.IDS_ONLY_FEAT_TYPES, args))
+        m.load_state_dict(G.params(s, base), strict=True)
+        m.to(DEV).train()
+        if drop:
+            m.multi_scale_encoder.cross_attention.dropout = 0.0          # not recordable in the reference: off there too
+            mods = dict(m.named_modules())
+            mults = G.block_drop_multipliers(s, p)
+            assert set(mults) == set(G.BLOCK_NAMES)
+            for name, mult in mults.items():
+                mods[name].fixed_drop_multiplier = mult.to(DEV)
+        _train_step_vs_fixture(s, p, m, "fused" + ("+drop" if drop else ""))
+    finally:
+        E.set_direct_param_grad(False)
+        ops.set_fused_table_grad(False)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("cls_name", ["HydraBlockFirst", "HydraBlock"])
+def test_fused_block_with_explicit_dropout_multiplier_vs_oracle(cls_name, d):
+    """One block in train mode on a given dropout multiplier (hydra3.py:411, 445: dropout sits before norm1; the
+    residual paths use the undropped input) against the oracle block with the same multiplier: forward, input
+    gradient and every parameter gradient."""
+    from generative_recommenders_amd import block_ops
+    assert block_ops.supported(d, 2)
+    B, L = 3, 21
+    torch.manual_seed(d + len(cls_name))
+    ref = getattr(O, cls_name)(d, 16, 4 * d, 16, O.make_args(d, L, dropout=0.3))
+    for q in ref.parameters():
+        if q.dim() >= 2:
+            torch.nn.init.xavier_normal_(q.data)
+        else:
+            q.data.add_(0.1 * torch.randn_like(q))
+    mine = getattr(H, cls_name)(d, 16, 4 * d, 16, H.make_args(d, L, dropout=0.3))
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.to(DEV).train()
+    ref.train()
+    pm = torch.ones(B, L, 1)
+    pm[1, :6] = 0
+    pm[2, :L - 1] = 0
+    x = torch.randn(B, L, d) * pm
+    mult = (torch.rand(B, L, d) >= 0.3).float() / 0.7
+    ref.dropout = G.FixedDropout(mult)
+    mine.fixed_drop_multiplier = mult.to(DEV)
+    xr, xd = x.clone().requires_grad_(), x.to(DEV).requires_grad_()
+    want, got = ref(xr, pm), mine(xd, pm.to(DEV))
+    close(got, want, 2e-3, 1e-3, "block output")
+    # the multiplier really was applied: without it the output differs
+    mine.fixed_drop_multiplier = torch.ones_like(mult).to(DEV)
+    with torch.no_grad():
+        plain = mine(xd, pm.to(DEV))
+    assert (plain.cpu() - want.detach()).abs().max().item() > 1e-2
+    g = torch.randn_like(want)
+    want.backward(g)
+    got.backward(g.to(DEV))
+    close(xd.grad, xr.grad, 4e-3, 2.5e-3, "dx")
+    pr, pd = dict(ref.named_parameters()), dict(mine.named_parameters())
+    assert set(pr) == set(pd)
+    for k, q in pr.items():
+        close(pd[k].grad, q.grad, 8e-3, 6.5e-3, "grad " + k)
+
+
 def test_train_step_with_its_own_sampling_stays_near_the_reference_loss():
     """Default path (negatives drawn on the GPU): same distribution, different draws -- the loss stays close."""
     s, p = G.load("g10_train"), "G10_train_small"

@@ -160,6 +160,48 @@ def test_train_step_loss_and_grads(name):
         assert float(g[0].abs().sum()) == 0.0
 
 
+def _train_step_matches(s, p, m):
+    b = {k: G.t(s, f"{p}/{k}") for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    torch.manual_seed(int(s[p + "/rng_seed"]))
+    loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, feat, feat, feat,
+             b["ts"], b["act"], b["dwell"])
+    loss.backward()
+    G.assert_close(loss, G.t(s, p + "/loss"), 2e-5, 2e-5, "loss")
+    gold = G.grads(s, p)
+    got = {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
+    tables = {k for k in got if k.endswith(("item_emb.weight", "user_emb.weight"))}
+    assert set(gold) == set(got) - tables
+    for k in gold:
+        G.assert_close(got[k], gold[k], 1e-3, 2e-5, "grad " + k)
+    for k in tables:
+        rows = G.t(s, f"{p}/grad_rows/{k}")
+        g = got[k]
+        assert torch.equal(g.abs().sum(1).nonzero().flatten(), rows), k
+        G.assert_close(g[rows], G.t(s, f"{p}/grad_vals/{k}"), 1e-3, 2e-5, "table grad " + k)
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_train_step_at_the_benchmark_width(drop):
+    """d = 64 (head_dim 32, inner width 128): the reference's train step without dropout, and with the blocks'
+    dropout applied through the multipliers the fixture recorded (attention-weight dropout off)."""
+    s = G.load("g14_train_d64")
+    base = "G14_train_d64"
+    p = base + ("_drop" if drop else "")
+    U, I, d, L = (int(s[f"{base}/{k}"]) for k in "UIdL")
+    args = O.make_args(d, L, dropout=0.0)
+    m = O.Hydra(U, I, {}, O.IDS_ONLY_FEAT_TYPES, args, O.SharedEmbeddingModule(U, I, {}, O.IDS_ONLY_FEAT_TYPES, args))
+    m.load_state_dict(G.params(s, base), strict=True)
+    m.train()
+    if drop:
+        mults = G.block_drop_multipliers(s, p)
+        assert set(mults) == set(G.BLOCK_NAMES)
+        mods = dict(m.named_modules())
+        for name, mult in mults.items():
+            mods[name].dropout = G.FixedDropout(mult)
+    _train_step_matches(s, p, m)
+
+
 @pytest.mark.parametrize("name", ["small", "chunky"])
 def test_recorded_draws_reproduce_the_reference_loss(name):
     """The fixture also holds what the reference drew (its torch.randint outputs and mined ids).  Assembled into
