@@ -140,6 +140,7 @@ struct PackLayout {
     size_t w1, w2, wg, wu, wd, win, wout, win_stride, wout_stride;
     // transposed: W1T .. WdT (d x d), WinT[h] (hd x 2 ED), WoutT[h] (ED x hd)
     size_t w1t, w2t, wgt, wut, wdt, wint, woutt, wint_stride, woutt_stride;
+    size_t vec;         // four d-vectors of floats (scale1, b1, b2, scale2) in the widened layout
     size_t total;
 };
 
@@ -160,17 +161,21 @@ __host__ __device__ inline PackLayout make_layout(int d, int H) {
     l.w2 = o; o += dd; l.wd = o; o += dd; l.wg = o; o += dd; l.wu = o; o += dd;
     l.wdt = o; o += dd; l.wgt = o; o += dd; l.wut = o; o += dd; l.w2t = o; o += dd;
     l.woutt_stride = pack_entries(l.ED, l.hd); l.woutt = o; o += l.woutt_stride * H;
+    l.vec = o; o += (size_t)d;          // 4 d floats = d entries of 16 bytes
     l.total = o;
     return l;
 }
 
+// A weight whose rows / columns come in groups that the packed image widens with zeros (head_dim 30 -> 32 and so on):
+// row n of the image is row (n / gNp) * gN + n % gNp of W when n % gNp < gN, a zero row otherwise; same for columns.
 struct PackJob {
-    const float* W;
+    const float* W;     // null: vector job (K = 1, plain floats at entry `out`)
     int64_t rs, cs;     // Wv(n, k) = W[n * rs + k * cs]
-    int N, K;
+    int N, K;           // image size
+    int gN, gNp, gK, gKp;
     size_t out;         // entry offset
 };
-constexpr int kMaxPackJobs = 2 * (5 + 2 * 8);
+constexpr int kMaxPackJobs = 2 * (5 + 2 * 8) + 4;
 struct PackParams {
     PackJob job[kMaxPackJobs];
     int n_jobs;
@@ -180,16 +185,29 @@ struct PackParams {
 // entry (nt, ks, part, lane): element j = Wv(32 nt + (lane & 31), 16 ks + 8 (j >> 2) + 4 (lane >> 5) + (j & 3))
 __global__ __launch_bounds__(256) void block_pack_kernel(PackParams p) {
     const PackJob& jb = p.job[blockIdx.y];
+    if (jb.gK == 0) {           // vector: image element n <- W[group-mapped n], plain fp32
+        float* dst = reinterpret_cast<float*>(p.out + jb.out);
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < jb.N; n += gridDim.x * 256) {
+            const int r = n % jb.gNp;
+            dst[n] = r < jb.gN ? jb.W[(n / jb.gNp) * jb.gN + r] : 0.f;
+        }
+        return;
+    }
     const int KS = (jb.K + 15) / 16, NTo = (jb.N + 31) / 32;
     const int n_frag = NTo * KS * 64;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n_frag; idx += gridDim.x * 256) {
         const int lane = idx & 63, ks = (idx >> 6) % KS, nt = (idx >> 6) / KS;
         const int n = 32 * nt + (lane & 31), h = lane >> 5;
+        const int nr = n % jb.gNp;
+        const bool n_ok = n < jb.N && nr < jb.gN;
+        const int64_t n_src = (int64_t)(n / jb.gNp) * jb.gN + nr;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
-            v[j] = (n < jb.N && k < jb.K) ? jb.W[(int64_t)n * jb.rs + (int64_t)k * jb.cs] : 0.f;
+            const int kr = k % jb.gKp;
+            const int64_t k_src = (int64_t)(k / jb.gKp) * jb.gK + kr;
+            v[j] = (n_ok && k < jb.K && kr < jb.gK) ? jb.W[n_src * jb.rs + k_src * jb.cs] : 0.f;
         }
         const Frag f = make_frag(v);
         uint4* e = p.out + jb.out + ((size_t)(nt * KS + ks) * 2) * 64 + lane;
@@ -203,6 +221,7 @@ struct BlockParams {
     int64_t T;
     int L, first;
     float eps, inv_sqrt_h;
+    float inv_d;            // 1 / (true model width): the RMSNorm means run over the true features of a widened layout
     PackLayout lay;
     const uint4* pk;
     unsigned lds_lo, lds_hi;  // entry range of the pack buffer a workgroup keeps in LDS (template flag LDSW)
@@ -266,7 +285,7 @@ __device__ __forceinline__ float norm1(const BlockParams& p, const float* xrow, 
         for (int r = 0; r < 16; ++r) ss += xd[nt][r] * xd[nt][r];
     }
     ss = pair_sum(ss);
-    const float rstd = 1.f / sqrtf(ss / (float)(32 * NT) + p.eps);
+    const float rstd = 1.f / sqrtf(ss * p.inv_d + p.eps);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         f32x16 sc;
@@ -456,7 +475,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void block_post_fwd_kernel(Bl
 #pragma unroll
             for (int r = 0; r < 16; ++r) ss += m[nt][r] * m[nt][r];
         ss = pair_sum(ss);
-        const float rstd2 = 1.f / sqrtf(ss / (float)d + p.eps);
+        const float rstd2 = 1.f / sqrtf(ss * p.inv_d + p.eps);
         f32x16 n2[NT];
         Frag nf[2 * NT];
 #pragma unroll
@@ -618,7 +637,7 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_post_bwd_kernel(Bloc
             for (int r = 0; r < 16; ++r) dot += dn2[nt][r] * sc[r] * mt[r];
         }
         dot = pair_sum(dot);
-        const float coef = dot * rstd2 * rstd2 / (float)d;
+        const float coef = dot * rstd2 * rstd2 * p.inv_d;
         Frag dmf[2 * NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -783,7 +802,7 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_pre_bwd_kernel(Block
             }
         }
         dot = pair_sum(dot);
-        const float coef = dot * rstd * rstd / (float)d;
+        const float coef = dot * rstd * rstd * p.inv_d;
         const float cres = p.first ? 1.f : 2.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -856,6 +875,16 @@ constexpr size_t kMaxWeightLds = 128 * 1024;
 // ================================================================================ C ABI
 extern "C" int hmx_block_supported(int64_t d, int64_t H) { return shape_ok(d, H) ? 1 : 0; }
 
+// Width the fused halves run a (d, H) block at: every head widened with zero features to the next multiple of 32
+// (d itself when d / H already is one); 0 when that width is not supported or head_dim is odd.
+extern "C" int64_t hmx_block_padded_width(int64_t d, int64_t H) {
+    if (H <= 0 || d <= 0 || d % H || (d / H) % 2) return 0;
+    const int64_t hdp = (d / H + 31) / 32 * 32, dp = hdp * H;
+    const int64_t EDp = 4 * hdp;
+    if (!shape_ok(dp, H) || (EDp & (EDp - 1))) return 0;     // the scan groups 4 * head_dim channels in powers of two
+    return dp;
+}
+
 extern "C" size_t hmx_block_packed_bytes(int64_t d, int64_t H) {
     if (!shape_ok(d, H)) return 0;
     return make_layout((int)d, (int)H).total * sizeof(uint4);
@@ -866,25 +895,40 @@ extern "C" int64_t hmx_block_scale_partial_rows(int64_t T) {
     return std::min<int64_t>(hmx_ceil_div(hmx_ceil_div(std::max<int64_t>(T, 1), 32), 8) * 8, 4096);
 }
 
-extern "C" int hmx_block_pack_f32(const hmx_block_weights* w, int64_t d, int64_t H, void* packed, void* stream) {
+extern "C" int hmx_block_pack_f32(const hmx_block_weights* w, int64_t d, int64_t H, int64_t d_real, void* packed,
+                                  void* stream) {
     HMX_ENTER();
     if (!w || !packed || !shape_ok(d, H)) return HMX_EINVAL;
     if (!w->W1 || !w->W2 || !w->Wg || !w->Wu || !w->Wd) return HMX_EINVAL;
+    if (d_real <= 0) d_real = d;
+    const bool widened = d_real != d;
+    if (widened && (d_real % H || hmx_block_padded_width(d_real, H) != d)) return HMX_EINVAL;
+    if (widened && (!w->scale1 || !w->b1 || !w->b2 || !w->scale2)) return HMX_EINVAL;
     const PackLayout l = make_layout((int)d, (int)H);
+    const int hd = (int)(d_real / H), ED = 4 * hd, D = (int)d_real;      // true sizes; l.* are the image's
     PackParams p{};
     int n = 0;
-    auto add = [&](const float* W, int64_t rs, int64_t cs, int N, int K, size_t out) { p.job[n++] = PackJob{W, rs, cs, N, K, out}; };
-    const int D = (int)d;
-    add(w->W1, D, 1, D, D, l.w1); add(w->W2, D, 1, D, D, l.w2); add(w->Wg, D, 1, D, D, l.wg);
-    add(w->Wu, D, 1, D, D, l.wu); add(w->Wd, D, 1, D, D, l.wd);
-    add(w->W1, 1, D, D, D, l.w1t); add(w->W2, 1, D, D, D, l.w2t); add(w->Wg, 1, D, D, D, l.wgt);
-    add(w->Wu, 1, D, D, D, l.wut); add(w->Wd, 1, D, D, D, l.wdt);
+    // (rs, cs): strides of the TRUE weight; (N, K): image size; (gN -> gNp), (gK -> gKp): widened groups per axis
+    auto add = [&](const float* W, int64_t rs, int64_t cs, int N, int K, int gN, int gNp, int gK, int gKp, size_t out) {
+        p.job[n++] = PackJob{W, rs, cs, N, K, gN, gNp, gK, gKp, out};
+    };
+    const int Dp = (int)d;
+    const float* sq[5] = {w->W1, w->W2, w->Wg, w->Wu, w->Wd};
+    const size_t sq_out[5] = {l.w1, l.w2, l.wg, l.wu, l.wd}, sq_out_t[5] = {l.w1t, l.w2t, l.wgt, l.wut, l.wdt};
+    for (int i = 0; i < 5; ++i) {
+        add(sq[i], D, 1, Dp, Dp, hd, l.hd, hd, l.hd, sq_out[i]);
+        add(sq[i], 1, D, Dp, Dp, hd, l.hd, hd, l.hd, sq_out_t[i]);
+    }
     for (int hh = 0; hh < (int)H; ++hh) {
         if (!w->Win[hh] || !w->Wout[hh]) return HMX_EINVAL;
-        add(w->Win[hh], l.hd, 1, 2 * l.ED, l.hd, l.win + hh * l.win_stride);            // (2 ED, hd)
-        add(w->Win[hh], 1, l.hd, l.hd, 2 * l.ED, l.wint + hh * l.wint_stride);          // transposed: (hd, 2 ED)
-        add(w->Wout[hh], l.ED, 1, l.hd, l.ED, l.wout + hh * l.wout_stride);             // (hd, ED)
-        add(w->Wout[hh], 1, l.ED, l.ED, l.hd, l.woutt + hh * l.woutt_stride);           // transposed: (ED, hd)
+        add(w->Win[hh], hd, 1, 2 * l.ED, l.hd, ED, l.ED, hd, l.hd, l.win + hh * l.win_stride);       // (2 ED, hd)
+        add(w->Win[hh], 1, hd, l.hd, 2 * l.ED, hd, l.hd, ED, l.ED, l.wint + hh * l.wint_stride);     // transposed
+        add(w->Wout[hh], ED, 1, l.hd, l.ED, hd, l.hd, ED, l.ED, l.wout + hh * l.wout_stride);        // (hd, ED)
+        add(w->Wout[hh], 1, ED, l.ED, l.hd, ED, l.ED, hd, l.hd, l.woutt + hh * l.woutt_stride);      // transposed
+    }
+    if (widened) {
+        const float* vec[4] = {w->scale1, w->b1, w->b2, w->scale2};
+        for (int i = 0; i < 4; ++i) add(vec[i], 0, 0, Dp, 1, hd, l.hd, 0, 0, l.vec + (size_t)i * (Dp / 4));
     }
     p.n_jobs = n;
     p.out = static_cast<uint4*>(packed);
@@ -898,6 +942,9 @@ static bool fill_common(BlockParams& p, const hmx_block_args* a) {
     p = BlockParams{};
     p.T = a->T; p.L = (int)a->L; p.first = a->first; p.eps = a->eps;
     p.inv_sqrt_h = 1.0f / sqrtf((float)a->H);
+    const int64_t d_real = a->d_real > 0 ? a->d_real : a->d;
+    if (d_real != a->d && hmx_block_padded_width(d_real, a->H) != a->d) return false;
+    p.inv_d = 1.0f / (float)d_real;
     p.lay = make_layout((int)a->d, (int)a->H);
     p.pk = static_cast<const uint4*>(a->packed);
     p.mask = a->mask; p.x = a->x; p.drop = a->drop; p.scale1 = a->scale1; p.b1 = a->b1; p.cs = a->rope_cos; p.sn = a->rope_sin;
@@ -905,6 +952,10 @@ static bool fill_common(BlockParams& p, const hmx_block_args* a) {
     p.out = a->out; p.m = a->m; p.rstd2 = a->rstd2; p.dout = a->dout; p.dyg = a->dyg; p.dy2 = a->dy2; p.dm = a->dm;
     p.hmid = a->hmid; p.n2 = a->n2; p.dg = a->dg; p.du = a->du; p.p = a->p; p.dy1 = a->dy1; p.dscale_part = a->dscale_part;
     p.dx_in = a->dx_in; p.dz = a->dz; p.dx = a->dx; p.s = a->s; p.dx1 = a->dx1; p.n = a->n;
+    if (d_real != a->d) {       // widened layout: the d-vectors come from the pack buffer (zero in the added features)
+        const float* vec = reinterpret_cast<const float*>(p.pk + p.lay.vec);
+        p.scale1 = vec; p.b1 = vec + a->d; p.b2 = vec + 2 * a->d; p.scale2 = vec + 3 * a->d;
+    }
     return true;
 }
 

@@ -380,12 +380,15 @@ def heads_linear(x, weights, rows=None):
 _ROPE_CACHE = {}
 
 
-def rope_tables(L, hd, device):
-    """cos/sin of t * 10000^(-2i/hd), t = 0..L-1 (hydra3.py:318-328), computed once on the CPU in fp32."""
-    key = (L, hd, str(device))
+def rope_tables(L, hd, device, pairs=None):
+    """cos/sin of t * 10000^(-2i/hd), t = 0..L-1 (hydra3.py:318-328), computed once on the CPU in fp32.
+    pairs > hd / 2: rows widened to `pairs` entries with the identity rotation (heads in a widened feature layout)."""
+    pairs = hd // 2 if pairs is None else pairs
+    key = (L, hd, pairs, str(device))
     if key not in _ROPE_CACHE:
         theta = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
         ang = torch.arange(L, dtype=torch.float32)[:, None] * theta[None, :]
+        ang = torch.nn.functional.pad(ang, (0, pairs - hd // 2))
         _ROPE_CACHE[key] = (torch.cos(ang).to(device).contiguous(), torch.sin(ang).to(device).contiguous())
     return _ROPE_CACHE[key]
 
@@ -478,42 +481,64 @@ class _ConvSilu(torch.autograd.Function):
         return dx, pg[:4 * C].view(C, 4), pg[4 * C:], None
 
 
+_ZEROS = {}
+
+
+def _zeros(n, device):
+    """A shared read-only block of n zeros."""
+    key = (str(device),)
+    z = _ZEROS.get(key)
+    if z is None or z.numel() < n:
+        z = _ZEROS[key] = torch.zeros(max(n, 4096), dtype=torch.float32, device=device)
+    return z[:n]
+
+
 class _HeadParams(torch.autograd.Function):
     """The per-head conv / scan parameters of a block, stacked over heads: one copy launch for all of them; the
-    gradients go back to the heads as slices of the stacked gradients (no launch)."""
+    gradients go back to the heads as slices of the stacked gradients (no launch).  rows > a head's own channel
+    count: every head's block is followed by zero rows up to `rows` channels (widened layout; zero parameters keep
+    the added channels at zero through conv and scan)."""
 
     @staticmethod
-    def forward(ctx, H, *params):
+    def forward(ctx, H, rows, *params):
         groups = [params[i:i + H] for i in range(0, len(params), H)]
-        flat = torch.cat([q.detach().reshape(-1) for q in params])
+        pieces = []
+        for q in params:
+            pieces.append(q.detach().reshape(-1))
+            extra = (rows - q.shape[0]) * (q.numel() // q.shape[0])
+            if extra:
+                pieces.append(_zeros(extra, q.device))
+        flat = torch.cat(pieces)
         outs, at = [], 0
         for g in groups:
-            n = sum(q.numel() for q in g)
-            outs.append(flat[at:at + n].view(H * g[0].shape[0], *g[0].shape[1:]))
+            n = H * rows * (g[0].numel() // g[0].shape[0])
+            outs.append(flat[at:at + n].view(H * rows, *g[0].shape[1:]))
             at += n
-        ctx.H = H
+        ctx.H, ctx.rows = H, rows
         ctx.shapes = [q.shape for q in params]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        H, out = ctx.H, []
+        H, rows, out = ctx.H, ctx.rows, []
         for gi, g in enumerate(grads):
             for h in range(H):
                 shape = ctx.shapes[gi * H + h]
-                out.append(None if g is None else g[h * shape[0]:(h + 1) * shape[0]].view(shape))
-        return (None, *out)
+                out.append(None if g is None else g[h * rows:h * rows + shape[0]].view(shape))
+        return (None, None, *out)
 
 
-def head_params(blocks):
+def head_params(blocks, rows=None):
     """(conv weight (C, 4), conv bias (C), W_dt (C, 16), b_dt (C), A_log (C, 16), D (C)) of the heads' MambaBlocks,
-    channels of head h at rows h * ED ... (h + 1) * ED."""
+    channels of head h at rows h * rows ... h * rows + ED (rows = ED unless given: see _HeadParams)."""
     per = [[m.conv1d.weight.view(m.conv1d.weight.shape[0], -1) for m in blocks], [m.conv1d.bias for m in blocks],
            [m.ssm.dt_proj_layer.weight for m in blocks], [m.ssm.dt_proj_layer.bias for m in blocks],
            [m.ssm.A_log for m in blocks], [m.ssm.D for m in blocks]]
-    if len(blocks) == 1:
+    ED = per[1][0].shape[0]
+    rows = ED if rows is None else rows
+    if len(blocks) == 1 and rows == ED:
         return tuple(g[0] for g in per)
-    return _HeadParams.apply(len(blocks), *[q for g in per for q in g])
+    return _HeadParams.apply(len(blocks), rows, *[q for g in per for q in g])
 
 
 def conv_silu(x, w, b, L):
@@ -571,18 +596,21 @@ class _ProjScan(torch.autograd.Function):
     input gradient is added into the scan's dxc by the product itself (xc feeds both, autograd would add them)."""
 
     @staticmethod
-    def forward(ctx, xc, z, Wdt, bdt, A_log, D, L, ED, H, *Wdbc):
+    def forward(ctx, xc, z, Wdt, bdt, A_log, D, L, ED, H, EDr, *Wdbc):
+        """ED: channels per head of xc / z / the stacked parameters; EDr <= ED: a head's true channel count, the
+        width of its deltaBC weight (48, EDr) -- channels EDr .. ED of a head are the zero channels of a widened
+        layout and do not enter the projection."""
         _need_cuda(xc, z)
         xc, Wdt, bdt, A_log, D = (_f32c(t) for t in (xc, Wdt, bdt, A_log, D))
         z = _f32c(z) if z is not None else None
         ws = [_f32c(q) for q in Wdbc]
         T, C = xc.shape
         B = T // L
-        if ED < 32 or ED & (ED - 1) or C != ED * H or len(ws) != H or any(w.shape != (P_DBC, ED) for w in ws):
+        if ED < 32 or ED & (ED - 1) or C != ED * H or len(ws) != H or any(w.shape != (P_DBC, EDr) for w in ws):
             raise hmx.HmxError(f"selective scan needs 4*head_dim to be a power of two >= 32 (got {ED})")
         dbc = _empty(T, H * P_DBC, like=xc)
         for h, w in enumerate(ws):
-            _linear_raw(xc.data_ptr() + 4 * h * ED, C, hmx.ptr(w), ED, 1, None, T, P_DBC, ED,
+            _linear_raw(xc.data_ptr() + 4 * h * ED, C, hmx.ptr(w), EDr, 1, None, T, P_DBC, EDr,
                         dbc.data_ptr() + 4 * h * P_DBC, H * P_DBC)
         keep = any(ctx.needs_input_grad)
         hs = _empty(max(int(_L().hmx_scan_state_floats(B, L, C)), 1), like=xc) if keep else None
@@ -591,14 +619,14 @@ class _ProjScan(torch.autograd.Function):
                                     hmx.ptr(D), B, L, C, ED, H, hmx.ptr(yg), hmx.ptr(hs), _s()), "hmx_scan_fwd")
         if keep:
             ctx.save_for_backward(xc, z, dbc, Wdt, bdt, A_log, D, hs, *ws)
-        ctx.dims = (B, L, C, ED, H)
+        ctx.dims = (B, L, C, ED, H, EDr)
         ctx.params = Wdbc
         return yg
 
     @staticmethod
     def backward(ctx, dyg):
         xc, z, dbc, Wdt, bdt, A_log, D, hs, *ws = ctx.saved_tensors
-        B, L, C, ED, H = ctx.dims
+        B, L, C, ED, H, EDr = ctx.dims
         T = B * L
         dyg = _f32c(dyg)
         gph = _L().hmx_scan_groups_per_head(ED)
@@ -618,22 +646,22 @@ class _ProjScan(torch.autograd.Function):
         dws = []
         for h, w in enumerate(ws):
             gp = ddbc.data_ptr() + 4 * h * P_DBC
-            _linear_raw(gp, H * P_DBC, hmx.ptr(w), 1, ED, None, T, ED, P_DBC, dxc.data_ptr() + 4 * h * ED, C,
+            _linear_raw(gp, H * P_DBC, hmx.ptr(w), 1, EDr, None, T, EDr, P_DBC, dxc.data_ptr() + 4 * h * ED, C,
                         accumulate=True)
-            if not ctx.needs_input_grad[9 + h]:
+            if not ctx.needs_input_grad[10 + h]:
                 dws.append(None)
                 continue
             tw = _param_grad_target(ctx.params[h])
             if tw is not None:
-                _wgrad_queue.add(ddbc, h * P_DBC, H * P_DBC, xc, h * ED, C, None, T, P_DBC, ED, tw, 0, ED, None, 0)
+                _wgrad_queue.add(ddbc, h * P_DBC, H * P_DBC, xc, h * ED, C, None, T, P_DBC, EDr, tw, 0, EDr, None, 0)
                 dws.append(None)
                 continue
             dw = torch.empty_like(w)
-            _wgrad_raw(gp, H * P_DBC, xc.data_ptr() + 4 * h * ED, C, None, T, P_DBC, ED, hmx.ptr(dw), ED, None, xc.device)
+            _wgrad_raw(gp, H * P_DBC, xc.data_ptr() + 4 * h * ED, C, None, T, P_DBC, EDr, hmx.ptr(dw), EDr, None, xc.device)
             dws.append(dw)
         pg = colsum(ppart)                   # [dA_log (C, 16) | dW_dt (C, 16) | db_dt (C) | dD (C)]
         return (dxc, dz, pg[16 * C:32 * C].view(C, 16), pg[32 * C:33 * C], pg[:16 * C].view(C, 16), pg[33 * C:],
-                None, None, None, *dws)
+                None, None, None, None, *dws)
 
 
 def _scan_width(ED):
@@ -665,18 +693,21 @@ def _padded_scan(xc, z, Wdt, bdt, A_log, D, L, ED, H, dbc=None, Wdbc=None):
     zp = _pad_channels(z, H, ED, EDp, 1) if z is not None else None
     Wdt, bdt, A_log, D = (_pad_channels(t, H, ED, EDp, 0) for t in (Wdt, bdt, A_log, D))
     if Wdbc is not None:
-        Wp = [torch.nn.functional.pad(w, (0, EDp - ED)) for w in Wdbc]
-        y = _ProjScan.apply(xcp, zp, Wdt, bdt, A_log, D, L, EDp, H, *Wp)
+        y = _ProjScan.apply(xcp, zp, Wdt, bdt, A_log, D, L, EDp, H, ED, *Wdbc)
     else:
         y = _Scan.apply(xcp, zp, dbc, Wdt, bdt, A_log, D, L, EDp, H)
     return y.reshape(T, H, EDp)[..., :ED].reshape(T, H * ED)
 
 
-def proj_scan_gated(xc, z, Wdbc, Wdt, bdt, A_log, D, L, ED, H):
-    """selective_scan_gated(xc, z, heads_linear(xc, Wdbc), ...): Wdbc is one (48, ED) deltaBC weight per head."""
+def proj_scan_gated(xc, z, Wdbc, Wdt, bdt, A_log, D, L, ED, H, ED_real=None):
+    """selective_scan_gated(xc, z, heads_linear(xc, Wdbc), ...): Wdbc is one (48, ED) deltaBC weight per head.
+    ED_real < ED: inputs and stacked parameters are already in a widened layout (ED channels per head, the last
+    ED - ED_real of them zero) and the deltaBC weights are the true (48, ED_real) ones."""
+    if ED_real is not None and ED_real != ED:
+        return _ProjScan.apply(xc, z, Wdt, bdt, A_log, D, L, ED, H, ED_real, *Wdbc)
     if ED != _scan_width(ED):
         return _padded_scan(xc, z, Wdt, bdt, A_log, D, L, ED, H, Wdbc=Wdbc)
-    return _ProjScan.apply(xc, z, Wdt, bdt, A_log, D, L, ED, H, *Wdbc)
+    return _ProjScan.apply(xc, z, Wdt, bdt, A_log, D, L, ED, H, ED, *Wdbc)
 
 
 def selective_scan_gated(xc, z, dbc, Wdt, bdt, A_log, D, L, ED, H):

@@ -22,7 +22,8 @@ class WgradDesc(ctypes.Structure):
 
 class BlockWeights(ctypes.Structure):
     """hmx_block_weights of include/hmx.h."""
-    _fields_ = [(n, c_void_p) for n in ("W1", "W2", "Wg", "Wu", "Wd")] + [("Win", c_void_p * 8), ("Wout", c_void_p * 8)]
+    _fields_ = ([(n, c_void_p) for n in ("W1", "W2", "Wg", "Wu", "Wd")] + [("Win", c_void_p * 8), ("Wout", c_void_p * 8)] +
+                [(n, c_void_p) for n in ("scale1", "b1", "b2", "scale2")])
 
 
 _BLOCK_PTRS_IN = ("mask", "x", "drop", "scale1", "b1", "rope_cos", "rope_sin")
@@ -35,7 +36,7 @@ class BlockArgs(ctypes.Structure):
                 [(n, c_void_p) for n in ("mask", "x", "drop", "scale1", "b1", "rope_cos", "rope_sin",
                                          "rstd1", "x_in", "z", "y2", "yg", "b2", "scale2", "out", "m", "rstd2", "dout",
                                          "dyg", "dy2", "dm", "hmid", "n2", "dg", "du", "p", "dy1", "dscale_part",
-                                         "dx_in", "dz", "dx", "s", "dx1", "n")])
+                                         "dx_in", "dz", "dx", "s", "dx1", "n")] + [("d_real", c_int64)])
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/hmx.h
@@ -103,7 +104,8 @@ PROTOTYPES = {
     "hmx_block_supported": (c_int, [I64, I64]),
     "hmx_block_packed_bytes": (c_size_t, [I64, I64]),
     "hmx_block_scale_partial_rows": (I64, [I64]),
-    "hmx_block_pack_f32": (c_int, [ctypes.POINTER(BlockWeights), I64, I64, P, P]),
+    "hmx_block_padded_width": (I64, [I64, I64]),
+    "hmx_block_pack_f32": (c_int, [ctypes.POINTER(BlockWeights), I64, I64, I64, P, P]),
     "hmx_block_pre_fwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
     "hmx_block_post_fwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
     "hmx_block_post_bwd": (c_int, [ctypes.POINTER(BlockArgs), P]),

@@ -19,7 +19,7 @@ from .enc_ops import pscan, selective_scan   # noqa: F401  (hydra3.py:104, 107: 
 from .shared_embedding import SharedEmbeddingConfig, SharedEmbeddingModule
 
 D_STATE, DT_RANK, D_CONV = 16, 16, 4
-FUSED_BLOCKS = True      # HydraBlock(First) on the fused block kernels where the shape allows (d, d / heads multiples of 32)
+FUSED_BLOCKS = True      # HydraBlock(First) on the fused block kernels where block_ops.Layout.of(d, heads) exists (d <= 128 after widening)
 
 
 class RMSNorm(nn.Module):
@@ -130,15 +130,30 @@ class _HydraBlockBase(nn.Module):
         self.norm1 = RMSNorm(dim)
         self.norm2 = RMSNorm(dim)
 
+    def fused_layout(self, device=None):
+        """The feature layout in which this block runs on the fused block kernels (block_ops.Layout), or None when it
+        takes the per-operation kernels (width not supported, single-bf16 mode, CPU tensors)."""
+        mhm = self.multiheadMamba
+        if not (FUSED_BLOCKS and hmx.SPLIT_BF16) or (device is not None and torch.device(device).type != "cuda"):
+            return None
+        return block_ops.Layout.of(mhm.linear_layer1.weight.shape[0], len(mhm.mamba))
+
     def forward(self, x, padding_mask):
+        """x (B, L, d) -> (B, L, d) (hydra3.py:410-423 / 444-457).  A stack of blocks whose layout is widened
+        (fused_layout().widened) may hand the widened (B, L, dp) tensor from block to block: an input of that width
+        is taken as widened already and the output keeps it."""
         B, L, d = x.shape
         T = B * L
         x2 = x.reshape(T, d)
         m1 = padding_mask.reshape(T).contiguous() if padding_mask is not None else None
         mhm = self.multiheadMamba
-        if FUSED_BLOCKS and x2.is_cuda and hmx.SPLIT_BF16 and block_ops.supported(d, len(mhm.mamba)):
+        lay = self.fused_layout(x.device)
+        if lay is not None:
             # the block as two fused token-parallel kernels around the conv / scan core
-            return block_ops.hydra_block(self, x2.contiguous(), m1, L, self.first).view(B, L, d)
+            if d == lay.dp:
+                return block_ops.hydra_block(self, x2.contiguous(), m1, L, self.first, lay).view(B, L, d)
+            out = block_ops.hydra_block(self, lay.widen(x2).contiguous(), m1, L, self.first, lay)
+            return lay.narrow(out).view(B, L, d)
         if self.training and self.dropout.p > 0.0 and self.fixed_drop_multiplier is not None:
             xd = E.mul_scale(x2, self.fixed_drop_multiplier.reshape(T, d).contiguous(), 1.0)
         else:
@@ -191,6 +206,10 @@ class MultiScaleUserEncoder(nn.Module):
         short = self.short_term_encoder(sequence[:, -sw:].contiguous(), sm)
         mid = self.mid_term_encoder(sequence[:, -mw:].contiguous(), mm)
         long_ = self.long_term_encoder(sequence, padding_mask)
+        lay = self.long_term_encoder.fused_layout(sequence.device)
+        if lay is not None and lay.widened and long_.shape[-1] == lay.dp:     # widened input: the tail runs at d
+            short, mid = (lay.narrow(t[:, -1]).unsqueeze(1) for t in (short, mid))
+            long_ = lay.narrow(long_.reshape(-1, lay.dp)).view(long_.shape[0], L, lay.d)
         B, _, d = long_.shape
         sf, mf, lf = short[:, -1].contiguous(), mid[:, -1].contiguous(), long_[:, -1].contiguous()
         # nn.MultiheadAttention(query=sf, key=value=long_) spelled out on the HIP kernels: in-projections,
@@ -490,10 +509,14 @@ class Hydra(nn.Module):
                 seq_feature = [f[cut:] for f in seq_feature]
         seqs, pm = self.assemble_inputs(log_seqs, mask, seq_timestamp, action_type, dwell_bins, seq_feature)
         B, L, d = seqs.shape
+        lay = self.hydra_first.fused_layout(seqs.device)
+        if lay is not None and lay.widened:
+            # the whole block stack runs in the widened layout: widened once here, narrowed once in the fusion tail
+            seqs = lay.widen(seqs.reshape(B * L, d)).view(B, L, lay.dp)
         # dropout multipliers of all blocks (full-length ones plus the 10- and 25-token windows) from one draw
-        n_drop = d * B * (L * (2 + len(self.hydra)) + min(10, L) + min(25, L))
+        n_drop = (lay.dp if lay is not None else d) * B * (L * (2 + len(self.hydra)) + min(10, L) + min(25, L))
         with block_ops.drop_pool(n_drop, self.args.hydra_dropout_rate, seqs.device,
-                                 enabled=self.training and seqs.is_cuda and FUSED_BLOCKS):
+                                 enabled=self.training and lay is not None):
             seqs = self.hydra_first(seqs, padding_mask=pm)
             for blk in self.hydra:
                 seqs = blk(x=seqs, padding_mask=pm)

@@ -378,11 +378,23 @@ int hmx_sum_groups_f32(const float* part, int64_t rows, int64_t groups, int64_t 
  * hmx_linear_wgrad_batch_f32, plus per-wave partials of the two RMSNorm scale gradients, shaped
  * (hmx_block_scale_partial_rows(T), d) (sum with hmx_colsum_f32).
  * One argument block serves the four calls; each reads the fields its half needs.
+ * Widened blocks.  A width whose head_dim is not a multiple of 32 -- the reference's default hidden size 60 gives
+ * head_dim 30 (main.py:54, :57) -- runs on the same kernels in a widened layout: every head's head_dim features are
+ * followed by zero features up to the next multiple of 32, every head's 4 * head_dim inner channels by zero channels
+ * up to 4 times that (60 -> 64, 240 -> 256).  hmx_block_padded_width(d_real, H) is the width d to pass everywhere
+ * (0: not supported; d_real itself: nothing to widen); hmx_block_pack_f32 takes the TRUE weights (shapes in d_real)
+ * and writes images with zero rows / columns at the added positions, plus widened copies of the four d-vectors, which
+ * the kernels then read instead of the scale1 / b1 / b2 / scale2 arguments; every activation argument is in the
+ * widened layout (the caller zero-fills the added features of x once; they stay zero through every block), and the
+ * RMSNorm means run over d_real.  Weight-gradient operands come out widened as well: the caller's
+ * hmx_wgrad_desc entries address the true sub-blocks (per head pair) of each product.
  * ------------------------------------------------------------------------------- */
 typedef struct hmx_block_weights {
     const float *W1, *W2, *Wg, *Wu, *Wd;   /* linear_layer1, linear_layer2, gate, up, down: (d, d)          */
     const float* Win[8];                   /* per head in_proj (2 * ED, hd), rows [x | z]                   */
     const float* Wout[8];                  /* per head out_proj (hd, ED)                                    */
+    const float *scale1, *b1, *b2, *scale2; /* (d) each: norm1.scale, linear_layer1.bias, linear_layer2.bias,
+                                              norm2.scale; read only when the block is packed widened        */
 } hmx_block_weights;
 typedef struct hmx_block_args {
     int64_t T, L, d, H;
@@ -397,11 +409,13 @@ typedef struct hmx_block_args {
     float *dyg, *dy2, *dm, *hmid, *n2, *dg, *du, *p, *dy1, *dscale_part;
     const float *dx_in, *dz;               /* pre backward inputs (T, H*ED) each                            */
     float *dx, *s, *dx1, *n;
+    int64_t d_real;                        /* true model width of a widened block (0 or d: not widened)     */
 } hmx_block_args;
 int hmx_block_supported(int64_t d, int64_t H);
+int64_t hmx_block_padded_width(int64_t d, int64_t H);
 size_t hmx_block_packed_bytes(int64_t d, int64_t H);
 int64_t hmx_block_scale_partial_rows(int64_t T);
-int hmx_block_pack_f32(const hmx_block_weights* w, int64_t d, int64_t H, void* packed, void* stream);
+int hmx_block_pack_f32(const hmx_block_weights* w, int64_t d, int64_t H, int64_t d_real, void* packed, void* stream);
 int hmx_block_pre_fwd(const hmx_block_args* a, void* stream);
 int hmx_block_post_fwd(const hmx_block_args* a, void* stream);
 int hmx_block_post_bwd(const hmx_block_args* a, void* stream);

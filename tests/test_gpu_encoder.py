@@ -22,6 +22,29 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=["fused-widened", "per-operation"])
+def block_path(request):
+    """Widths whose head_dim is not a multiple of 32 (d = 16: 8, d = 60: 30) run on the fused block halves in a
+    widened layout by default; with the switch off they take the per-operation kernels (padded scan channels).  Tests
+    that use this fixture run on both and check which one ran."""
+    from generative_recommenders_amd import block_ops
+    calls = []
+    real = block_ops.hydra_block
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    old = block_ops.PAD_TO_FUSED
+    block_ops.PAD_TO_FUSED = request.param == "fused-widened"
+    block_ops.hydra_block = counting
+    try:
+        yield request.param
+    finally:
+        block_ops.PAD_TO_FUSED = old
+        block_ops.hydra_block = real
+    assert (len(calls) > 0) == (request.param == "fused-widened"), (request.param, len(calls))
+
+
 def close(got, ref, mx=2e-3, rms=1e-3, what=""):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     assert got.shape == ref.shape, f"{what}: {tuple(got.shape)} vs {tuple(ref.shape)}"
@@ -126,12 +149,12 @@ def test_d128_widths_golden():
 
 
 @pytest.mark.parametrize("name,cls", [("first", H.HydraBlockFirst), ("regular", H.HydraBlock)])
-def test_hydra_blocks_golden(name, cls):
+def test_hydra_blocks_golden(name, cls, block_path):
     run_module_case(G.load("g6_blocks"), f"G6_block_{name}", cls(16, 16, 64, 16, H.make_args(16, 14)), 2)
 
 
 @pytest.mark.parametrize("L", [2, 7, 10, 25, 26, 40])
-def test_multiscale_golden(L):
+def test_multiscale_golden(L, block_path):
     m = H.MultiScaleUserEncoder(16, 16, 64, 16, H.make_args(16, L))
     run_module_case(G.load("g7_multiscale"), f"G7_multiscale_L{L}", m, 2)
 
@@ -174,7 +197,7 @@ def test_input_assembly_is_fp32_tight():
 
 
 @pytest.mark.parametrize("name", ["small", "chunky"])
-def test_train_step_against_reference_golden(name):
+def test_train_step_against_reference_golden(name, block_path):
     """A whole Hydra.forward + backward against what the reference produced for the same step.  The reference draws
     its negatives from the CPU generator, which a GPU cannot replay, so the fixture carries the draws themselves
     (its torch.randint outputs and its mined ids) and the step runs on them: the loss must agree to 1e-4 and EVERY
@@ -262,14 +285,15 @@ def test_train_step_on_the_fused_block_kernels_against_reference_golden(drop, di
         ops.set_fused_table_grad(False)
 
 
-@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("d", [64, 128, 60, 24, 100])
 @pytest.mark.parametrize("cls_name", ["HydraBlockFirst", "HydraBlock"])
 def test_fused_block_with_explicit_dropout_multiplier_vs_oracle(cls_name, d):
     """One block in train mode on a given dropout multiplier (hydra3.py:411, 445: dropout sits before norm1; the
     residual paths use the undropped input) against the oracle block with the same multiplier: forward, input
     gradient and every parameter gradient."""
     from generative_recommenders_amd import block_ops
-    assert block_ops.supported(d, 2)
+    lay = block_ops.Layout.of(d, 2)
+    assert lay is not None and lay.widened == (d % 64 != 0)
     B, L = 3, 21
     torch.manual_seed(d + len(cls_name))
     ref = getattr(O, cls_name)(d, 16, 4 * d, 16, O.make_args(d, L, dropout=0.3))
@@ -692,9 +716,11 @@ def test_rerank_candidates_and_auxiliary_losses():
     assert ids.shape == (5, 4) and int(ids.min()) >= 0 and int(ids.max()) < 10
 
 
-def test_log2feats_and_grads_vs_oracle_reference_default_width():
-    """d = 60 (the reference's default hidden size: head_dim 30, inner width 120, neither a power of two), L = 20,
-    B = 4 with ragged left padding; eval mode.  Forward and every parameter gradient against the CPU oracle."""
+def test_log2feats_and_grads_vs_oracle_reference_default_width(block_path):
+    """d = 60 (the reference's default hidden size, main.py:54: head_dim 30, inner width 120, neither a power of two),
+    L = 20, B = 4 with ragged left padding; eval mode.  Forward and every parameter gradient against the CPU oracle,
+    on the fused block halves (features widened 30 -> 32 per head inside the kernels' layout) and on the
+    per-operation kernels."""
     from generative_recommenders_amd import synth
     U, I, d, L, B = 200, 900, 60, 20, 4
     ref = O.build_model(U, I, d=d, L=L, seed=31).eval()
@@ -721,7 +747,7 @@ def test_log2feats_and_grads_vs_oracle_reference_default_width():
     assert checked > 100
 
 
-def test_train_step_runs_at_the_reference_default_width():
+def test_train_step_runs_at_the_reference_default_width(block_path):
     """A whole train step (encoder, top-50 miner, fused InfoNCE, backward) at d = 60: same distribution of draws as
     the oracle's step on the same batch and weights, so the loss stays close; every gradient is finite and the
     padding rows of both tables receive none."""
@@ -747,9 +773,9 @@ def test_train_step_runs_at_the_reference_default_width():
     assert float(se.item_emb.weight.grad[0].abs().sum()) == 0.0 and float(se.user_emb.weight.grad[0].abs().sum()) == 0.0
 
 
-def test_training_loop_gradient_modes_at_the_reference_default_width():
-    """The two opt-in gradient modes of the training loop at d = 60 (padded scan channels, unfused block path): same
-    loss, same gradients as autograd accumulation on the same draws (same torch seed)."""
+def test_training_loop_gradient_modes_at_the_reference_default_width(block_path):
+    """The two opt-in gradient modes of the training loop at d = 60 (both block paths): same loss, same gradients as
+    autograd accumulation on the same draws (same torch seed)."""
     from generative_recommenders_amd import ops, synth
     U, I, d, L, B = 200, 3000, 60, 20, 16
     bt = synth.train_batch(B, L, U, I, DEV, seed=52)
