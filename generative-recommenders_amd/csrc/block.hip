@@ -849,9 +849,7 @@ constexpr size_t kMaxWeightLds = 128 * 1024;
         if ((hi) > (lo) && lds_bytes <= kMaxWeightLds) {                                                             \
             (p).lds_lo = (unsigned)(lo);                                                                             \
             (p).lds_hi = (unsigned)(hi);                                                                             \
-            static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL<NTV, true>),   \
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxWeightLds); \
-            (void)attr_;                                                                                             \
+            hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&KERNEL<NTV, true>), (int)kMaxWeightLds);            \
             hipLaunchKernelGGL((KERNEL<NTV, true>), dim3(std::min(block_grid(T, WAVES), 256)), dim3(64 * (WAVES)),   \
                                lds_bytes, stream, p);                                                                \
         } else {                                                                                                     \

@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <atomic>
 
+#include <mutex>
+
 #include "hmx_common.h"
 #include "profile.h"
 
@@ -414,7 +416,7 @@ struct WgradParams {
 
 // Arrival counters of the in-launch reduction below: one word per output tile of a launch, in a slot chosen by the
 // host per call.  They are zero whenever no launch is in flight: the workgroup that arrives last puts its counter
-// back to zero.  (Concurrent launches from several streams take different slots, sixteen of them.)
+// back to zero.  (A slot belongs to one stream of one GPU at a time, see wgrad_tickets_for_call.)
 constexpr int kWgradMaxTiles = 1024;
 constexpr int kWgradSlots = 16;
 __device__ unsigned g_wgrad_tickets[kWgradSlots * kWgradMaxTiles];
@@ -1267,18 +1269,45 @@ static int64_t wgrad_tiles(int64_t N, int64_t K, bool with_bias) {
     return hmx_ceil_div(N, 32) * hmx_ceil_div(K + (with_bias ? 1 : 0), 32);
 }
 
-static int wgrad_tickets_for_call(unsigned** out) {
-    static std::atomic<unsigned> next_slot{0};
-    static std::atomic<unsigned*> ticket_base[64];      // per device: each GPU has its own copy of the array
+// The counters of a launch: the slot that belongs to the launch's (device, stream).  Launches on one stream run one
+// after the other, so they can share a slot (each leaves its counters at zero); launches on different streams of a
+// GPU may overlap and must not.  Sixteen streams per GPU hold a slot at a time; a seventeenth takes over the slot
+// whose stream launched longest ago.
+static int wgrad_tickets_for_call(hipStream_t stream, unsigned** out) {
+    struct Slots {
+        unsigned* base = nullptr;
+        hipStream_t owner[kWgradSlots] = {};
+        uint64_t last_use[kWgradSlots] = {};
+        int used = 0;
+    };
+    static Slots per_device[64];          // each GPU has its own copy of the array
+    static std::mutex mu;
+    static uint64_t clock = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return HMX_ELAUNCH;
-    unsigned* tickets = ticket_base[dev].load();
-    if (tickets == nullptr) {
+    std::lock_guard<std::mutex> lock(mu);
+    Slots& sl = per_device[dev];
+    if (sl.base == nullptr) {
+        unsigned* tickets = nullptr;
         if (hipGetSymbolAddress(reinterpret_cast<void**>(&tickets), HIP_SYMBOL(g_wgrad_tickets)) != hipSuccess || !tickets)
             return HMX_ELAUNCH;
-        ticket_base[dev].store(tickets);
+        sl.base = tickets;
     }
-    *out = tickets + (size_t)(next_slot.fetch_add(1) % kWgradSlots) * kWgradMaxTiles;
+    int slot = -1;
+    for (int i = 0; i < sl.used; ++i)
+        if (sl.owner[i] == stream) slot = i;
+    if (slot < 0) {
+        if (sl.used < kWgradSlots) {
+            slot = sl.used++;
+        } else {
+            slot = 0;
+            for (int i = 1; i < kWgradSlots; ++i)
+                if (sl.last_use[i] < sl.last_use[slot]) slot = i;
+        }
+        sl.owner[slot] = stream;
+    }
+    sl.last_use[slot] = ++clock;
+    *out = sl.base + (size_t)slot * kWgradMaxTiles;
     return HMX_OK;
 }
 
@@ -1317,7 +1346,7 @@ extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n
     if (tiles > kWgradMaxTiles) return HMX_EINVAL;
     p.n_jobs = nj;
     p.part = static_cast<float*>(workspace);
-    const int rc = wgrad_tickets_for_call(&p.tickets);
+    const int rc = wgrad_tickets_for_call((hipStream_t)stream, &p.tickets);
     if (rc != HMX_OK) return rc;
     const int64_t G = wgrad_groups(t_max, tiles);
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
@@ -1686,12 +1715,8 @@ extern "C" int hmx_scan_bwd(const float* xc, const float* xz, const float* dbc, 
     q.GPH = (int)hmx_scan_groups_per_head(ED);
     const dim3 grid((unsigned)B, (unsigned)hmx_ceil_div(C, 256));
     const size_t lds = (size_t)kCk * 4 * 256 * sizeof(float4) + (size_t)kScanChunkBwd * H * kP * 4;
-    static const hipError_t attr64 = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_kernel<64>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr32 = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_kernel<32>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr64;
-    (void)attr32;
+    hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&scan_bwd_kernel<64>), 160 * 1024);
+    hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&scan_bwd_kernel<32>), 160 * 1024);
     if (lds > 160 * 1024) return HMX_EINVAL;
     void* span = hmx_profile_begin("scan_bwd", (hipStream_t)stream);
     if (ED >= 64) hipLaunchKernelGGL(scan_bwd_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, q);

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "../../include/hmx.h"
 
 #define HMX_WAVE 64
@@ -16,6 +20,19 @@
         hipError_t e_ = hipGetLastError();            \
         if (e_ != hipSuccess) return HMX_ELAUNCH;     \
     } while (0)
+
+// Raises a kernel's dynamic-LDS limit, once per (kernel, device): the attribute belongs to the kernel's image on the
+// device that is current when it is set, so a process that uses several GPUs sets it on each.  Not capture-safe on
+// the first call for a (kernel, device); later calls only look the pair up.
+inline void hmx_allow_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.insert({kernel, dev}).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 __host__ __device__ static inline int64_t hmx_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t hmx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -594,17 +594,11 @@ int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64
             hipLaunchKernelGGL((segment_sum_balanced_kernel<VEC, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
                                n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
         } else {
-            static const hipError_t attr = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&segment_sum_staged_kernel<VEC, Src>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                kMaxStagedLds);
-            (void)attr;
+            hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&segment_sum_staged_kernel<VEC, Src>), kMaxStagedLds);
             hipLaunchKernelGGL((segment_sum_staged_kernel<VEC, Src>), dim3((unsigned)n_sb), dim3(kBlock), lds, s, src, skeys,
                                svals, n, (int)cpr, l2, S, stage_bytes, sentinel, table, head_piece, tail_piece);
         }
-        static const hipError_t jattr = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&segment_join_kernel<VEC, SB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            (kBlock / 64) * kJoinLdsPerWave);
-        (void)jattr;
+        hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&segment_join_kernel<VEC, SB>), (kBlock / 64) * kJoinLdsPerWave);
         hipLaunchKernelGGL((segment_join_kernel<VEC, SB>), dim3(grid4), dim3(kBlock), (kBlock / 64) * kJoinLdsPerWave, s, skeys,
                            n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
     };

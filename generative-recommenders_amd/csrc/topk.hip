@@ -1257,9 +1257,7 @@ void launch_bf16(const CoarseParams& p, hipStream_t s) {
     if constexpr ((KS == 4 || KS == 8) && NB * KS <= 16) {   // query fragments of a wave fit 64 registers
         if (ring_enabled() && p.n_qtiles % kRingWaves == 0 && p.ring_error != nullptr) {
             constexpr int lds = kStages * kStageBytes;
-            static const hipError_t attr = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&coarse_bf16_ring_kernel<NB, KP, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)attr;
+            hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&coarse_bf16_ring_kernel<NB, KP, KS>), lds);
             hipLaunchKernelGGL((coarse_bf16_ring_kernel<NB, KP, KS>), dim3((p.n_qtiles / kRingWaves) * p.n_splits),
                                dim3(64 * kRingWaves), lds, s, p);
             return;

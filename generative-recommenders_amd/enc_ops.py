@@ -137,6 +137,7 @@ class GradArena:
             self.total += (q.numel() + 63) // 64 * 64
         self.buf = None
         self.views = []
+        self.handed = set()      # slots handed out from the current buffer
 
     def alive(self):
         return any(slot[2]() is not None for slot in self.offsets.values())
@@ -149,7 +150,13 @@ class GradArena:
         if self.buf is None or all(v() is None for v in self.views) or self.buf.device != param.device:
             self.buf = torch.zeros(self.total, dtype=torch.float32, device=param.device)
             self.views = []
+            self.handed = set()
         g = self.buf[slot[0]:slot[0] + slot[1]].view(param.shape)
+        if slot[0] in self.handed:
+            # this parameter's slice was in use before (its .grad was dropped while another view of the buffer is
+            # still held, e.g. a partial zero_grad or a logger keeping a gradient): it holds the old gradient
+            g.zero_()
+        self.handed.add(slot[0])
         import weakref
         self.views.append(weakref.ref(g))
         return g
@@ -186,7 +193,7 @@ def _param_grad_target(param):
 
 class _WgradQueue:
     def __init__(self):
-        self.jobs, self.keep, self.targets, self.armed, self.tiles = [], [], set(), False, 0
+        self.jobs, self.keep, self.targets, self.tiles = [], [], set(), 0
 
     def add(self, dy, dy_off, ldy, x, x_off, ldx, in_mask, T, N, K, dw, dw_off, ldw, db, db_off):
         """dW[dw_off ...] += dY^T X (and dbias += column sums of dY); offsets are in elements."""
@@ -206,16 +213,18 @@ class _WgradQueue:
             self.targets.add(tb)
         self.stream = _s()
         self.device = dy.device
-        if not self.armed:
-            try:   # runs when the backward pass that is executing now has finished
-                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
-                self.armed = True
+        if len(self.jobs) == 1:
+            # first job since the queue was last emptied: ask for a flush when the backward pass that is executing now
+            # has finished.  (Registered per filling, not once per pass: a pass that raises never runs its callbacks,
+            # and a flag that only a callback clears would then stay set for good.)
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
             except RuntimeError:
                 self.flush()          # not inside a backward pass: nothing to wait for
 
-    def _end_of_backward(self):
-        self.armed = False
-        self.flush()
+    def discard(self):
+        """Drops queued products without running them: what a backward pass that raised left behind."""
+        self.jobs, self.keep, self.targets, self.tiles = [], [], set(), 0
 
     def flush(self):
         if not self.jobs:
@@ -235,6 +244,13 @@ _wgrad_queue = _WgradQueue()
 def flush_deferred_wgrads():
     """Run the queued weight-gradient products now (a backward pass does this by itself when it ends)."""
     _wgrad_queue.flush()
+
+
+def discard_stale_wgrads():
+    """Called where a new training forward pass starts: a backward pass that completed has flushed its queue, so
+    anything still queued belongs to a pass that raised part-way; its products must not be added to the gradients of
+    the step that starts now."""
+    _wgrad_queue.discard()
 
 
 # ------------------------------------------------------------------------------- linear

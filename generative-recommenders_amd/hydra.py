@@ -19,6 +19,7 @@ from .enc_ops import pscan, selective_scan   # noqa: F401  (hydra3.py:104, 107: 
 from .shared_embedding import SharedEmbeddingConfig, SharedEmbeddingModule
 
 D_STATE, DT_RANK, D_CONV = 16, 16, 4
+VALIDATE_HARD_GROUPS = False   # debug switch: verify on the device that broadcast hard-negative lists repeat per sequence
 FUSED_BLOCKS = True      # HydraBlock(First) on the fused block kernels where block_ops.Layout.of(d, heads) exists (d <= 128 after widening)
 
 
@@ -372,10 +373,21 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
             ch = ch.repeat(1, (num_hard + K - 1) // K)[:, :num_hard]
             # one list per user, broadcast over its positions (Hydra.forward): the rows of a user are consecutive in
             # the masked order and share their ids, which the loss backward can use
+            # Contract of the grouped path: hard_negatives is ONE (B, K) list per sequence broadcast over the positions
+            # (stride(1) == 0 says exactly that for the tensor as it arrives); hard ids that differ between the
+            # positions of a sequence must come as a dense (B, L, K) tensor.  VALIDATE_HARD_GROUPS re-checks it on
+            # the device (one comparison + a host sync per call).
             if hard_negatives.dim() == 3 and hard_negatives.stride(1) == 0 and K <= 64 and q.is_cuda:
                 starts = torch.zeros(mask.shape[0] + 1, dtype=torch.int64, device=device)
                 starts[1:] = mask.sum(1).cumsum(0)
                 hard_groups = (starts, K)
+                if VALIDATE_HARD_GROUPS:
+                    seq_of_row = torch.div(rows, mask.shape[1], rounding_mode="floor")
+                    first = ch.index_select(0, starts[:-1].clamp(max=max(M - 1, 0)).index_select(0, seq_of_row))
+                    period_ok = torch.equal(ch, ch[:, :K].repeat(1, (num_hard + K - 1) // K)[:, :num_hard])
+                    if not (period_ok and torch.equal(ch, first)):
+                        raise hmx.HmxError("hard negatives are not one periodic list per sequence: pass a dense "
+                                           "(B, L, K) tensor instead of a broadcast view")
         hard_ids = ch
     inb = None
     if num_inb > 0:                                                      # hydra3.py:921-950
@@ -563,6 +575,7 @@ class Hydra(nn.Module):
         here only when their weights are non-zero (the loss value and every gradient are the same either way).
         predrawn: see compute_mixed_contrastive_loss.  The mined hard-negative ids of the call are kept in
         self.last_mined_ids."""
+        E.discard_stale_wgrads()
         log_feats = self.log2feats(user_item, seq_feature, mask, timestamp, action_type, dwell_bins)
         se = self.shared_embeddings
         item_table = se.item_emb.weight

@@ -94,7 +94,10 @@ int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const i
  * ends; the call allocates nothing.  Inputs whose hmx_scatter_add_rows_workspace_bytes(n, n_rows, d) exceeds that
  * size (about 1,000,000 ids at d = 64) are refused with HMX_ELIMIT and nothing is enqueued.  Result: bit-identical to
  * hmx_scatter_add_rows_f32.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
- * (different streams or threads) race; calls on one stream, or on different GPUs, do not. */
+ * (different streams or threads) race; calls on one stream, or on different GPUs, do not.
+ * The first call on a GPU looks up the array's address and raises two kernels' dynamic-LDS limits (HIP module
+ * calls that are not allowed under stream capture): make one call per GPU (any size, n = 1 will do) before
+ * capturing a graph that contains this entry point. */
 size_t hmx_scatter_add_rows_static_scratch_bytes(void);
 int hmx_scatter_add_rows_f32_static(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
                                     int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
@@ -269,8 +272,9 @@ int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, in
 /* Weight / bias gradient on fp32 MFMA: dW[n * ldw + k] = sum_t dY[t, n] * X[t, k] * in_rowmask[t],
  * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  One launch: token splits write partial tiles to the workspace and
  * the workgroup that finishes a tile last adds them in split order (deterministic, no float atomics).  The arrival
- * counters of that hand-over live inside the library (zero between launches); up to sixteen launches may be in
- * flight at once on different streams. */
+ * counters of that hand-over live inside the library (zero between launches), one set per (GPU, stream): launches on
+ * up to sixteen streams of a GPU may be in flight at once (a seventeenth stream takes over the set of the stream
+ * that launched longest ago, whose launch must have completed by then). */
 typedef struct hmx_wgrad_desc {
     const float* dY;          /* (T, N) with row stride ldy                                   */
     int64_t ldy;

@@ -867,3 +867,97 @@ def test_training_loop_exactly_as_the_reference_script_drives_it():
     assert all(math.isfinite(l) for l in losses), losses
     moved = sum(int(not torch.equal(before[k], q.detach())) for k, q in model.named_parameters())
     assert moved > 100, moved
+
+
+def test_gradient_buffer_slices_are_cleared_when_reused_while_other_views_live():
+    """Direct-gradient mode hands out .grad tensors as views of one flat buffer.  When one sub-module's gradients
+    are dropped (zero_grad(set_to_none=True)) while something else still holds a view of that buffer, the buffer is
+    reused: the re-issued slices must start from zero, not from the previous step's values."""
+    from generative_recommenders_amd import ops
+    s, p = G.load("g10_train"), "G10_train_small"
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    hard, inb = G.assemble_train_draws(s, p, G.t(s, p + "/next_tok") == 1)
+    try:
+        E.set_direct_param_grad(True)
+        ops.set_fused_table_grad(True)
+        m = _model_from(s, p, dropout=0.0).train()
+
+        def step():
+            loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, feat, feat, feat, b["ts"], b["act"],
+                     b["dwell"], predrawn=(hard.to(DEV), inb.to(DEV)))
+            loss.backward()
+        step()
+        first = {k: q.grad.clone() for k, q in m.hydra_first.named_parameters() if q.grad is not None}
+        held = m.hydra_projection.weight.grad            # an outside reference keeps the buffer alive
+        assert len(first) > 10 and held is not None
+        m.hydra_first.zero_grad(set_to_none=True)         # partial: only this sub-module
+        step()
+        for k, q in m.hydra_first.named_parameters():
+            if k in first:
+                close(q.grad, first[k], 2e-5, 2e-5, "re-issued gradient slice " + k)
+        # everything else accumulated a second, equal step on top of the first
+        twice = m.hydra_projection.weight.grad.clone()
+        m.zero_grad(set_to_none=True)
+        step()
+        close(twice, 2 * m.hydra_projection.weight.grad, 2e-5, 2e-5, "accumulated")
+    finally:
+        E.set_direct_param_grad(False)
+        ops.set_fused_table_grad(False)
+
+
+def test_weight_gradient_queue_recovers_from_a_backward_pass_that_raised():
+    """Direct-gradient mode queues weight-gradient products and runs them when the backward pass ends.  A pass that
+    raises leaves its products queued; the next training step drops them (they belong to the failed step) and its own
+    products are flushed at the end of its own backward pass."""
+    try:
+        E.set_direct_param_grad(True)
+        W = torch.nn.Parameter(torch.randn(16, 32, device=DEV))
+        x = torch.randn(40, 32, device=DEV, requires_grad=True)
+
+        class Boom(RuntimeError):
+            pass
+
+        def explode(_):
+            raise Boom()
+        y = E.linear(x, W)
+        h = x.register_hook(explode)
+        with pytest.raises(Boom):
+            y.sum().backward()
+        h.remove()
+        assert len(E._wgrad_queue.jobs) == 1               # the failed pass left its product behind
+        E.discard_stale_wgrads()                           # what Hydra.forward does when a training step starts
+        assert len(E._wgrad_queue.jobs) == 0
+        W.grad = None
+        x2 = torch.randn(40, 32, device=DEV)
+        gy = torch.randn(40, 16, device=DEV)
+        E.linear(x2, W).backward(gy)
+        assert len(E._wgrad_queue.jobs) == 0               # flushed by this pass's own end-of-backward callback
+        close(W.grad, gy.t() @ x2, 1e-3, 1e-3, "dW after recovery")
+        # and without the explicit drop: a later pass still flushes at its own end (nothing stays armed)
+        y = E.linear(x, W)
+        h = x.register_hook(explode)
+        with pytest.raises(Boom):
+            y.sum().backward()
+        h.remove()
+        E.linear(x2, W).backward(gy)
+        assert len(E._wgrad_queue.jobs) == 0
+    finally:
+        E._wgrad_queue.discard()
+        E.set_direct_param_grad(False)
+
+
+def test_hard_negative_group_contract_can_be_validated():
+    """The grouped loss backward relies on one mined list per sequence broadcast over its positions; the debug switch
+    re-checks that on the device and accepts what Hydra.forward builds."""
+    s, p = G.load("g10_train"), "G10_train_small"
+    m = _model_from(s, p, dropout=0.0).train()
+    b = {k: G.t(s, f"{p}/{k}").to(DEV) for k in ("seq", "pos", "neg", "tok", "next_tok", "ts", "act", "dwell")}
+    feat = [[] for _ in range(b["seq"].shape[0])]
+    H.VALIDATE_HARD_GROUPS = True
+    try:
+        torch.manual_seed(0)
+        loss = m(b["seq"], b["pos"], b["neg"], b["tok"], b["next_tok"], None, feat, feat, feat, b["ts"], b["act"], b["dwell"])
+        assert torch.isfinite(loss)
+    finally:
+        H.VALIDATE_HARD_GROUPS = False
