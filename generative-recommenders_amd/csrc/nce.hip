@@ -41,6 +41,8 @@ struct NceParams {
     float* k_inv;             // (m)
     const float* grad_row_loss;   // (m)   backward only
     float* dq;                    // (m, d) backward only
+    float* dq_unit;               // (m, d) or null.  Forward: receives d row_loss[i] / d q[i] (the gradient for a unit
+                                  // upstream gradient), accumulated during the one key walk; backward: its source
     int period;                   // > 0: hard_ids[i, s] == hard_ids[i, s % period]; only the first `period` hard slots
                                   // are evaluated, each weighted by the number of slots it stands for
 };
@@ -134,7 +136,7 @@ struct WalkSteps {
     static constexpr int value = NCH <= 2 ? 4 : (NCH == 4 ? 2 : 1);   // steps of 16 keys whose loads are in flight together
 };
 
-template <int NCH>
+template <int NCH, bool TRAIN>
 __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
     constexpr int kSteps = WalkSteps<NCH>::value;
     const int lane = threadIdx.x & 63, kg = lane >> 2, sub = lane & 3;
@@ -152,6 +154,11 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
         qv[ch] = make_float4(v.x * qs, v.y * qs, v.z * qs, v.w * qs);
     }
     float mx = -INFINITY, sm = 0.f, l0 = 0.f;
+    // TRAIN: acc = sum over this quad's keys of copies * exp(logit - mx) * key / |key| (the soft-max weighted key sum
+    // of the query's gradient), kept on the same running maximum as sm
+    float4 acc[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) acc[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c0 = 0; c0 < walk.n_walk; c0 += 16 * kSteps) {
         KeyRef ref[kSteps];
         float4 v[kSteps][NCH];
@@ -189,10 +196,26 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
                 // running maximum, rescaled only when it moves (a handful of times per query): one hardware
                 // exponential per key instead of two library ones.  exp(-inf) = 0 on the first key.
                 if (logit > mx) {
-                    sm *= __expf(mx - logit);
+                    const float down = __expf(mx - logit);
+                    sm *= down;
+                    if (TRAIN) {
+#pragma unroll
+                        for (int ch = 0; ch < NCH; ++ch) acc[ch] = vscale(down, acc[ch]);
+                    }
                     mx = logit;
                 }
-                sm += walk.copies(vs) * __expf(logit - mx);
+                const float w = walk.copies(vs) * __expf(logit - mx);
+                sm += w;
+                if (TRAIN) {
+                    const float wk = w * inv;
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        acc[ch].x += wk * v[u][ch].x;
+                        acc[ch].y += wk * v[u][ch].y;
+                        acc[ch].z += wk * v[u][ch].z;
+                        acc[ch].w += wk * v[u][ch].w;
+                    }
+                }
                 if (slot == 0) l0 = logit;
             }
         }
@@ -202,9 +225,18 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
     for (int off = 4; off <= 32; off <<= 1) {
         const float om = __shfl_xor(mx, off), os = __shfl_xor(sm, off);
         const float nm = fmaxf(mx, om);
-        const float a = (mx == -INFINITY) ? 0.f : sm * __expf(mx - nm);
-        const float b = (om == -INFINITY) ? 0.f : os * __expf(om - nm);
-        sm = a + b;
+        const float fa = (mx == -INFINITY) ? 0.f : __expf(mx - nm);
+        const float fb = (om == -INFINITY) ? 0.f : __expf(om - nm);
+        sm = sm * fa + os * fb;
+        if (TRAIN) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                acc[ch].x = acc[ch].x * fa + __shfl_xor(acc[ch].x, off) * fb;
+                acc[ch].y = acc[ch].y * fa + __shfl_xor(acc[ch].y, off) * fb;
+                acc[ch].z = acc[ch].z * fa + __shfl_xor(acc[ch].z, off) * fb;
+                acc[ch].w = acc[ch].w * fa + __shfl_xor(acc[ch].w, off) * fb;
+            }
+        }
         mx = nm;
     }
     l0 = __shfl(l0, 0);
@@ -212,6 +244,64 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(NceParams p) {
         const float lse = mx + logf(sm);
         p.lse[i] = lse;
         p.row_loss[i] = lse - l0;
+    }
+    if (TRAIN) {
+        // d row_loss / d qn = (sum_c softmax_c keyn_c - keyn_0) / temperature; through qn = q / max(|q|, eps) as in
+        // nce_bwd_q_kernel.  Every quad holds the wave's totals; the first one writes.
+        const float qinv = p.q_inv[i], kinv = p.k_inv[i], rs = 1.0f / sm, temp = 1.0f / p.inv_temp;
+        float4 qn[NCH];
+        float pr = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = sub + 4 * ch;
+            float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < p.cpr) k0 = reinterpret_cast<const float4*>(p.k)[i * p.cpr + c];
+            acc[ch].x = (acc[ch].x * rs - k0.x * kinv) * p.inv_temp;
+            acc[ch].y = (acc[ch].y * rs - k0.y * kinv) * p.inv_temp;
+            acc[ch].z = (acc[ch].z * rs - k0.z * kinv) * p.inv_temp;
+            acc[ch].w = (acc[ch].w * rs - k0.w * kinv) * p.inv_temp;
+            qn[ch] = vscale(temp, qv[ch]);
+            pr += dot4(qn[ch], acc[ch]);
+        }
+        pr = quad_sum(pr);
+        if (!p.normalize || qinv >= 1.0f / kNormEps) pr = 0.f;
+        if (kg == 0) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = sub + 4 * ch;
+                if (c < p.cpr) {
+                    float4 o;
+                    o.x = qinv * (acc[ch].x - qn[ch].x * pr);
+                    o.y = qinv * (acc[ch].y - qn[ch].y * pr);
+                    o.z = qinv * (acc[ch].z - qn[ch].z * pr);
+                    o.w = qinv * (acc[ch].w - qn[ch].w * pr);
+                    reinterpret_cast<float4*>(p.dq_unit)[i * p.cpr + c] = o;
+                }
+            }
+        }
+    }
+}
+
+// Backward without a key walk, for a forward pass that left dq_unit: dq[i] = grad_row_loss[i] * dq_unit[i], and the
+// walked columns of `logits` become the key-gradient coefficients (what nce_bwd_q_kernel leaves there):
+//   coef[i, c] = (softmax_c - [c == 0]) * copies(c) * grad_row_loss[i] / temperature * q_inv[i].
+// One wave per query row.
+__global__ __launch_bounds__(256) void nce_bwd_light_kernel(NceParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.m) return;
+    const int C = 1 + p.n_hard + p.n_inb;
+    const SlotWalk walk(p);
+    const float gr = p.grad_row_loss[i], lse = p.lse[i];
+    const float g = gr * p.inv_temp * p.q_inv[i];
+    float* row = p.logits + i * C;
+    for (int vs = lane; vs < walk.n_walk; vs += 64) {
+        const int slot = walk.real(vs);
+        row[slot] = (__expf(row[slot] - lse) - (slot == 0 ? 1.f : 0.f)) * g * walk.copies(vs);
+    }
+    for (int c = lane; c < p.cpr; c += 64) {
+        const float4 u = reinterpret_cast<const float4*>(p.dq_unit)[i * p.cpr + c];
+        reinterpret_cast<float4*>(p.dq)[i * p.cpr + c] = vscale(gr, u);
     }
 }
 
@@ -485,26 +575,33 @@ bool aligned16(const void* a) { return (reinterpret_cast<uintptr_t>(a) & 15) == 
 static int nce_fwd_impl(const float* q, const float* k, int64_t m, int64_t d, const float* table,
                         int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
                         int64_t n_inb, int64_t period, float temperature, int normalize, float* logits, float* row_loss,
-                        float* lse, float* q_inv, float* k_inv, void* stream) {
+                        float* lse, float* q_inv, float* k_inv, float* dq_unit, void* stream) {
     if (m == 0) return HMX_OK;
     if (period < 0 || period > n_hard) return HMX_EINVAL;
     if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb) || !(temperature > 0.f)) return HMX_EINVAL;
     if (!q || !k || !logits || !row_loss || !lse || !q_inv || !k_inv) return HMX_EINVAL;
     if ((n_hard > 0 && (!table || !hard_ids)) || (n_inb > 0 && !inb_idx)) return HMX_EINVAL;
-    if (!aligned16(q) || !aligned16(k) || (n_hard > 0 && !aligned16(table))) return HMX_EINVAL;
+    if (!aligned16(q) || !aligned16(k) || (n_hard > 0 && !aligned16(table)) || !aligned16(dq_unit)) return HMX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize,
                               logits, row_loss, lse, q_inv, k_inv);
     p.period = (int)period;
+    p.dq_unit = dq_unit;
     const unsigned g16 = (unsigned)hmx_ceil_div(m, 16), g4 = (unsigned)hmx_ceil_div(m, 4);
     hipLaunchKernelGGL(inv_norm_kernel, dim3(g16), dim3(256), 0, s, q, m, p.cpr, normalize, q_inv);
     hipLaunchKernelGGL(inv_norm_kernel, dim3(g16), dim3(256), 0, s, k, m, p.cpr, normalize, k_inv);
     void* span = hmx_profile_begin("nce_fwd", s);
-    if (p.cpr <= 4) hipLaunchKernelGGL(nce_fwd_kernel<1>, dim3(g4), dim3(256), 0, s, p);
-    else if (p.cpr <= 8) hipLaunchKernelGGL(nce_fwd_kernel<2>, dim3(g4), dim3(256), 0, s, p);
-    else if (p.cpr <= 16) hipLaunchKernelGGL(nce_fwd_kernel<4>, dim3(g4), dim3(256), 0, s, p);
-    else if (p.cpr <= 32) hipLaunchKernelGGL(nce_fwd_kernel<8>, dim3(g4), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(nce_fwd_kernel<16>, dim3(g4), dim3(256), 0, s, p);
+#define HMX_NCE_FWD(NCH)                                                                                  \
+    do {                                                                                                  \
+        if (dq_unit) hipLaunchKernelGGL((nce_fwd_kernel<NCH, true>), dim3(g4), dim3(256), 0, s, p);       \
+        else hipLaunchKernelGGL((nce_fwd_kernel<NCH, false>), dim3(g4), dim3(256), 0, s, p);              \
+    } while (0)
+    if (p.cpr <= 4) HMX_NCE_FWD(1);
+    else if (p.cpr <= 8) HMX_NCE_FWD(2);
+    else if (p.cpr <= 16) HMX_NCE_FWD(4);
+    else if (p.cpr <= 32) HMX_NCE_FWD(8);
+    else HMX_NCE_FWD(16);
+#undef HMX_NCE_FWD
     hmx_profile_end(span, s);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
@@ -513,21 +610,21 @@ static int nce_fwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
 extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
                                int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
                                int64_t n_inb, float temperature, int normalize, float* logits, float* row_loss,
-                               float* lse, float* q_inv, float* k_inv, void* stream) {
+                               float* lse, float* q_inv, float* k_inv, float* dq_unit, void* stream) {
     HMX_ENTER();
     return nce_fwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, 0, temperature, normalize, logits,
-                        row_loss, lse, q_inv, k_inv, stream);
+                        row_loss, lse, q_inv, k_inv, dq_unit, stream);
 }
 
 extern "C" int hmx_nce_fwd_periodic_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
                                         int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, int64_t period,
                                         const int64_t* inb_idx, int64_t n_inb, float temperature, int normalize,
                                         float* logits, float* row_loss, float* lse, float* q_inv, float* k_inv,
-                                        void* stream) {
+                                        float* dq_unit, void* stream) {
     HMX_ENTER();
     if (period <= 0) return HMX_EINVAL;
     return nce_fwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, period, temperature, normalize, logits,
-                        row_loss, lse, q_inv, k_inv, stream);
+                        row_loss, lse, q_inv, k_inv, dq_unit, stream);
 }
 
 namespace {
@@ -556,8 +653,8 @@ extern "C" size_t hmx_nce_bwd_grouped_workspace_bytes(int64_t m, int64_t d, int6
 static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, const float* table,
                         int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
                         int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
-                        const float* q_inv, const float* k_inv, const float* grad_row_loss, float* dq,
-                        float* dk, float* dtable, const int64_t* group_start, int64_t n_groups, int64_t period,
+                        const float* q_inv, const float* k_inv, const float* grad_row_loss, const float* dq_unit,
+                        float* dq, float* dk, float* dtable, const int64_t* group_start, int64_t n_groups, int64_t period,
                         void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return HMX_OK;
     const bool grouped = group_start != nullptr && n_hard > 0;
@@ -578,11 +675,15 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
                               const_cast<float*>(k_inv));
     p.grad_row_loss = grad_row_loss;
     p.dq = dq;
+    p.dq_unit = const_cast<float*>(dq_unit);
     p.period = grouped ? (int)period : 0;
     const int C = (int)(1 + n_hard + n_inb);
     const unsigned g16 = (unsigned)hmx_ceil_div(m, 16), g4 = (unsigned)hmx_ceil_div(m, 4);
     void* span = hmx_profile_begin("nce_bwd", s);
-    if (p.cpr <= 4) hipLaunchKernelGGL(nce_bwd_q_kernel<1>, dim3(g4), dim3(256), 0, s, p);
+    if (dq_unit != nullptr) {
+        if (!aligned16(dq_unit)) return HMX_EINVAL;
+        hipLaunchKernelGGL(nce_bwd_light_kernel, dim3(g4), dim3(256), 0, s, p);
+    } else if (p.cpr <= 4) hipLaunchKernelGGL(nce_bwd_q_kernel<1>, dim3(g4), dim3(256), 0, s, p);
     else if (p.cpr <= 8) hipLaunchKernelGGL(nce_bwd_q_kernel<2>, dim3(g4), dim3(256), 0, s, p);
     else if (p.cpr <= 16) hipLaunchKernelGGL(nce_bwd_q_kernel<4>, dim3(g4), dim3(256), 0, s, p);
     else if (p.cpr <= 32) hipLaunchKernelGGL(nce_bwd_q_kernel<8>, dim3(g4), dim3(256), 0, s, p);
@@ -637,22 +738,25 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
 extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
                                int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
                                int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
-                               const float* q_inv, const float* k_inv, const float* grad_row_loss, float* dq,
-                               float* dk, float* dtable, void* workspace, size_t workspace_bytes, void* stream) {
+                               const float* q_inv, const float* k_inv, const float* grad_row_loss,
+                               const float* dq_unit, float* dq, float* dk, float* dtable, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     HMX_ENTER();
     return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize, logits, lse,
-                        q_inv, k_inv, grad_row_loss, dq, dk, dtable, nullptr, 0, 0, workspace, workspace_bytes, stream);
+                        q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, nullptr, 0, 0, workspace, workspace_bytes,
+                        stream);
 }
 
 extern "C" int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
                                        int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
                                        int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
-                                       const float* q_inv, const float* k_inv, const float* grad_row_loss, float* dq,
-                                       float* dk, float* dtable, const int64_t* group_start, int64_t n_groups,
-                                       int64_t period, void* workspace, size_t workspace_bytes, void* stream) {
+                                       const float* q_inv, const float* k_inv, const float* grad_row_loss,
+                                       const float* dq_unit, float* dq, float* dk, float* dtable,
+                                       const int64_t* group_start, int64_t n_groups, int64_t period, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     HMX_ENTER();
     if (n_hard > 0 && !group_start) return HMX_EINVAL;
     return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize, logits, lse,
-                        q_inv, k_inv, grad_row_loss, dq, dk, dtable, group_start, n_groups, period, workspace,
+                        q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, group_start, n_groups, period, workspace,
                         workspace_bytes, stream);
 }

@@ -176,6 +176,9 @@ def gather_routed(item_weight, user_weight, ids, token_type):
 
 
 # --------------------------------------------------------------------------- fused InfoNCE
+FUSE_NCE_QUERY_GRAD = True    # the forward's key walk also accumulates d loss / d q (False: the backward walks the keys again)
+
+
 class _FusedNCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, table, hard_ids, inb_idx, temperature, normalize, hard_groups):
@@ -192,6 +195,8 @@ class _FusedNCE(torch.autograd.Function):
         logits = torch.empty(m, 1 + n_hard + n_inb, dtype=torch.float32, device=dev)
         row_loss, lse, q_inv, k_inv = (torch.empty(m, dtype=torch.float32, device=dev) for _ in range(4))
         n_rows = 0 if tab is None else tab.shape[0]
+        # with a gradient wanted, the forward's key walk also accumulates d loss_i / d q_i; the backward then needs no walk
+        dq_unit = torch.empty_like(q) if (FUSE_NCE_QUERY_GRAD and any(ctx.needs_input_grad[:3])) else None
         groups = None
         if hard_groups is not None and n_hard > 0:
             gs, period = hard_groups
@@ -204,14 +209,14 @@ class _FusedNCE(torch.autograd.Function):
             hmx.check(hmx.lib().hmx_nce_fwd_periodic_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid),
                                                          n_hard, groups[1], hmx.ptr(iid), n_inb, float(temperature),
                                                          int(bool(normalize)), hmx.ptr(logits), hmx.ptr(row_loss),
-                                                         hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv),
+                                                         hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(dq_unit),
                                                          hmx.current_stream()), "hmx_nce_fwd_periodic_f32")
         else:
             hmx.check(hmx.lib().hmx_nce_fwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
                                                 hmx.ptr(iid), n_inb, float(temperature), int(bool(normalize)),
                                                 hmx.ptr(logits), hmx.ptr(row_loss), hmx.ptr(lse), hmx.ptr(q_inv),
-                                                hmx.ptr(k_inv), hmx.current_stream()), "hmx_nce_fwd_f32")
-        ctx.save_for_backward(q, k, tab, hid, iid, logits, lse, q_inv, k_inv)
+                                                hmx.ptr(k_inv), hmx.ptr(dq_unit), hmx.current_stream()), "hmx_nce_fwd_f32")
+        ctx.save_for_backward(q, k, tab, hid, iid, logits, lse, q_inv, k_inv, dq_unit)
         ctx.cfg = (float(temperature), int(bool(normalize)), n_rows, n_hard, n_inb)
         ctx.table_param = table
         ctx.groups = groups
@@ -219,7 +224,7 @@ class _FusedNCE(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_rows):
-        q, k, tab, hid, iid, logits, lse, q_inv, k_inv = ctx.saved_tensors
+        q, k, tab, hid, iid, logits, lse, q_inv, k_inv, dq_unit = ctx.saved_tensors
         temperature, normalize, n_rows, n_hard, n_inb = ctx.cfg
         m, d = q.shape
         dev = q.device
@@ -244,15 +249,15 @@ class _FusedNCE(torch.autograd.Function):
             ws = workspace(L.hmx_nce_bwd_grouped_workspace_bytes(m, d, n_rows, n_hard, n_inb, ng, period), dev)
             hmx.check(L.hmx_nce_bwd_grouped_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
                                                 hmx.ptr(iid), n_inb, temperature, normalize, hmx.ptr(coef), hmx.ptr(lse),
-                                                hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq), hmx.ptr(dk),
-                                                hmx.ptr(dtable), hmx.ptr(gs), ng, period, hmx.ptr(ws), ws.numel(),
+                                                hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq_unit), hmx.ptr(dq),
+                                                hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(gs), ng, period, hmx.ptr(ws), ws.numel(),
                                                 hmx.current_stream()), "hmx_nce_bwd_grouped_f32")
         else:
             ws = workspace(L.hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb), dev)
             hmx.check(L.hmx_nce_bwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
                                         hmx.ptr(iid), n_inb, temperature, normalize, hmx.ptr(coef), hmx.ptr(lse),
-                                        hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq), hmx.ptr(dk),
-                                        hmx.ptr(dtable), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
+                                        hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq_unit), hmx.ptr(dq),
+                                        hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
                       "hmx_nce_bwd_f32")
         return dq, dk, (dtable if (want_table and fused_dst is None) else None), None, None, None, None, None
 

@@ -194,6 +194,11 @@ int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_
  * x^ = x / max(|x|, 1e-12) when normalize != 0 (F.normalize), else x.  An id / index out of range is a zero key.
  * The caller draws hard_ids and inb_idx (any sampling policy) and takes the mean of row_loss.
  * Forward leaves logits (m, 1 + n_hard + n_inb), lse (m), q_inv (m), k_inv (m) for the backward pass.
+ * dq_unit (m, d), optional (NULL: not wanted): the forward's one walk over the keys also accumulates
+ * d row_loss[i] / d q[i] (soft-max weighted key sum on a running maximum, then the normalisation Jacobian) and leaves
+ * it there; a backward call that is given the same buffer forms dq = grad_row_loss[i] * dq_unit[i] and the key
+ * coefficients from logits and lse without walking the keys a second time.  With NULL in both calls the backward
+ * walks the keys again (same values up to fp32 summation order).
  * Backward takes grad_row_loss (m) and produces dq (m, d), dk (m, d) (both overwritten) and, when n_hard > 0,
  * ADDS the hard-negative gradient rows into dtable (n_rows, d), which must be zero on entry (the normalisation
  * Jacobian is applied in place to the rows it touched).  `logits` is overwritten.  d % 4 == 0, d <= 256,
@@ -202,13 +207,13 @@ int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_
 int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
                     const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
                     float temperature, int normalize, float* logits, float* row_loss, float* lse, float* q_inv,
-                    float* k_inv, void* stream);
+                    float* k_inv, float* dq_unit, void* stream);
 size_t hmx_nce_bwd_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb);
 int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
                     const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
                     float temperature, int normalize, float* logits, const float* lse, const float* q_inv,
-                    const float* k_inv, const float* grad_row_loss, float* dq, float* dk, float* dtable,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    const float* k_inv, const float* grad_row_loss, const float* dq_unit, float* dq, float* dk,
+                    float* dtable, void* workspace, size_t workspace_bytes, void* stream);
 /* Hard negatives that repeat, which is how hydra3.py:905-919 builds them (each user's K mined ids, tiled over the n_hard
  * slots of all of that user's positions).
  * hmx_nce_fwd_periodic_f32: the caller guarantees hard_ids[i, s] == hard_ids[i, s % period] for every row; only the
@@ -223,14 +228,14 @@ int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const 
 int hmx_nce_fwd_periodic_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
                              const int64_t* hard_ids, int64_t n_hard, int64_t period, const int64_t* inb_idx,
                              int64_t n_inb, float temperature, int normalize, float* logits, float* row_loss, float* lse,
-                             float* q_inv, float* k_inv, void* stream);
+                             float* q_inv, float* k_inv, float* dq_unit, void* stream);
 size_t hmx_nce_bwd_grouped_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb,
                                            int64_t n_groups, int64_t period);
 int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
                             const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
                             float temperature, int normalize, float* logits, const float* lse, const float* q_inv,
-                            const float* k_inv, const float* grad_row_loss, float* dq, float* dk, float* dtable,
-                            const int64_t* group_start, int64_t n_groups, int64_t period, void* workspace,
+                            const float* k_inv, const float* grad_row_loss, const float* dq_unit, float* dq, float* dk,
+                            float* dtable, const int64_t* group_start, int64_t n_groups, int64_t period, void* workspace,
                             size_t workspace_bytes, void* stream);
 
 /* =================================================================================

@@ -8,6 +8,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["grad-in-forward-walk", "second-walk"])
+def query_grad_path(request):
+    """The query gradient either rides on the forward's key walk (default) or comes from a second walk in the
+    backward pass; every test of this file runs both ways."""
+    from generative_recommenders_amd import ops
+    old = ops.FUSE_NCE_QUERY_GRAD
+    ops.FUSE_NCE_QUERY_GRAD = request.param == "grad-in-forward-walk"
+    yield request.param
+    ops.FUSE_NCE_QUERY_GRAD = old
+
+
 def _case(M, d, R, n_hard, n_inb, seed, users=None, zero_rows=False):
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(M, d, generator=g)
