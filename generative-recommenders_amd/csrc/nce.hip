@@ -28,9 +28,11 @@ struct NceParams {
     int d, cpr;               // cpr = d / 4
     const float* table;       // (n_rows, d)
     int64_t n_rows;
-    const int64_t* hard_ids;  // (m, n_hard)
-    int n_hard;
-    const int64_t* inb_idx;   // (m, n_inb)
+    const int64_t* hard_ids;  // (m, hard_ld): the first min(n_hard, hard_ld) hard slots of every row
+    int n_hard, hard_ld;
+    const int64_t* inb_idx;   // (m, n_inb) int64, or null when inb32 is given
+    const int32_t* inb32;     // (m, n_inb) int32
+    int inb_skip_self;        // inb32 holds draws r in [0, m - 1): the key is row r + (r >= i)
     int n_inb;
     float inv_temp;
     int normalize;
@@ -106,13 +108,20 @@ __device__ __forceinline__ KeyRef locate_key(const NceParams& p, int64_t i, int 
         r.inv = p.k_inv[i];
         r.kind = 1;
     } else if (slot <= p.n_hard) {
-        const int64_t id = p.hard_ids[i * p.n_hard + slot - 1];
+        const int64_t id = p.hard_ids[i * p.hard_ld + slot - 1];
         if (id >= 0 && id < p.n_rows) {
             r.src = reinterpret_cast<const float4*>(p.table) + id * p.cpr;
             r.kind = 2;
         }
     } else {
-        const int64_t j = p.inb_idx[i * p.n_inb + slot - 1 - p.n_hard];
+        const int64_t at = i * p.n_inb + slot - 1 - p.n_hard;
+        int64_t j;
+        if (p.inb32 != nullptr) {
+            j = p.inb32[at];
+            if (p.inb_skip_self) j += (j >= i) ? 1 : 0;
+        } else {
+            j = p.inb_idx[at];
+        }
         if (j >= 0 && j < p.m) {
             r.src = reinterpret_cast<const float4*>(p.k) + j * p.cpr;
             r.inv = p.k_inv[j];
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(256) void nce_project_table_rows_kernel(const uint3
 // group's rows in order -- K rows per group to scatter instead of n_hard per query.
 constexpr int kMaxPeriod = 64;
 __global__ __launch_bounds__(256) void nce_group_rows_kernel(const float* __restrict__ q, const float* __restrict__ coef,
-                                                             int64_t m, int C, int n_hard, int K, int summed,
+                                                             int64_t m, int C, int n_hard, int hard_ld, int K, int summed,
                                                              const int64_t* __restrict__ group_start,
                                                              const int64_t* __restrict__ hard_ids, int cpr,
                                                              float* __restrict__ out_rows, int64_t* __restrict__ out_ids) {
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(256) void nce_group_rows_kernel(const float* __rest
     int64_t r0 = group_start[g], r1 = group_start[g + 1];
     r0 = r0 < 0 ? 0 : (r0 > m ? m : r0);
     r1 = r1 < r0 ? r0 : (r1 > m ? m : r1);
-    if (threadIdx.x < K) out_ids[g * K + threadIdx.x] = (r1 > r0) ? hard_ids[r0 * n_hard + threadIdx.x] : -1;
+    if (threadIdx.x < K) out_ids[g * K + threadIdx.x] = (r1 > r0) ? hard_ids[r0 * hard_ld + threadIdx.x] : -1;
     for (int c = lc; c < cpr; c += 16) {
         float4 acc[UMAX];
 #pragma unroll
@@ -543,9 +552,9 @@ bool nce_shape_ok(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t 
 }
 
 NceParams make_params(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
-                      const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
-                      float temperature, int normalize, float* logits, float* row_loss, float* lse, float* q_inv,
-                      float* k_inv) {
+                      const int64_t* hard_ids, int64_t n_hard, const void* inb_idx, int64_t n_inb, int64_t hard_ld,
+                      int64_t inb_flags, float temperature, int normalize, float* logits, float* row_loss, float* lse,
+                      float* q_inv, float* k_inv) {
     NceParams p{};
     p.q = q;
     p.k = k;
@@ -556,7 +565,13 @@ NceParams make_params(const float* q, const float* k, int64_t m, int64_t d, cons
     p.n_rows = n_rows;
     p.hard_ids = hard_ids;
     p.n_hard = (int)n_hard;
-    p.inb_idx = inb_idx;
+    p.hard_ld = (int)(hard_ld > 0 ? hard_ld : n_hard);
+    if (inb_flags & HMX_NCE_INB_I32) {
+        p.inb32 = static_cast<const int32_t*>(inb_idx);
+        p.inb_skip_self = (inb_flags & HMX_NCE_INB_SKIP_SELF) ? 1 : 0;
+    } else {
+        p.inb_idx = static_cast<const int64_t*>(inb_idx);
+    }
     p.n_inb = (int)n_inb;
     p.inv_temp = 1.0f / temperature;
     p.normalize = normalize;
@@ -570,21 +585,31 @@ NceParams make_params(const float* q, const float* k, int64_t m, int64_t d, cons
 
 bool aligned16(const void* a) { return (reinterpret_cast<uintptr_t>(a) & 15) == 0; }
 
+// hard_ld: row stride of hard_ids (0 = n_hard); it may be shorter than n_hard only when the slots beyond it repeat
+// (period <= hard_ld).  skip-self draws need int32 indices.
+bool index_args_ok(int64_t n_hard, int64_t hard_ld, int64_t period, int64_t inb_flags) {
+    if (hard_ld < 0 || (inb_flags & ~(int64_t)(HMX_NCE_INB_I32 | HMX_NCE_INB_SKIP_SELF))) return false;
+    if ((inb_flags & HMX_NCE_INB_SKIP_SELF) && !(inb_flags & HMX_NCE_INB_I32)) return false;
+    if (hard_ld > 0 && hard_ld < (period > 0 ? period : n_hard)) return false;
+    return true;
+}
+
 }  // namespace
 
 static int nce_fwd_impl(const float* q, const float* k, int64_t m, int64_t d, const float* table,
-                        int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
-                        int64_t n_inb, int64_t period, float temperature, int normalize, float* logits, float* row_loss,
-                        float* lse, float* q_inv, float* k_inv, float* dq_unit, void* stream) {
+                        int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const void* inb_idx,
+                        int64_t n_inb, int64_t hard_ld, int64_t inb_flags, int64_t period, float temperature, int normalize,
+                        float* logits, float* row_loss, float* lse, float* q_inv, float* k_inv, float* dq_unit,
+                        void* stream) {
     if (m == 0) return HMX_OK;
-    if (period < 0 || period > n_hard) return HMX_EINVAL;
+    if (period < 0 || period > n_hard || !index_args_ok(n_hard, hard_ld, period, inb_flags)) return HMX_EINVAL;
     if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb) || !(temperature > 0.f)) return HMX_EINVAL;
     if (!q || !k || !logits || !row_loss || !lse || !q_inv || !k_inv) return HMX_EINVAL;
     if ((n_hard > 0 && (!table || !hard_ids)) || (n_inb > 0 && !inb_idx)) return HMX_EINVAL;
     if (!aligned16(q) || !aligned16(k) || (n_hard > 0 && !aligned16(table)) || !aligned16(dq_unit)) return HMX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize,
-                              logits, row_loss, lse, q_inv, k_inv);
+    NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, hard_ld, inb_flags, temperature,
+                              normalize, logits, row_loss, lse, q_inv, k_inv);
     p.period = (int)period;
     p.dq_unit = dq_unit;
     const unsigned g16 = (unsigned)hmx_ceil_div(m, 16), g4 = (unsigned)hmx_ceil_div(m, 4);
@@ -608,23 +633,24 @@ static int nce_fwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
 }
 
 extern "C" int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
-                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
-                               int64_t n_inb, float temperature, int normalize, float* logits, float* row_loss,
-                               float* lse, float* q_inv, float* k_inv, float* dq_unit, void* stream) {
+                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const void* inb_idx,
+                               int64_t n_inb, int64_t hard_ld, int64_t inb_flags, float temperature, int normalize,
+                               float* logits, float* row_loss, float* lse, float* q_inv, float* k_inv, float* dq_unit,
+                               void* stream) {
     HMX_ENTER();
-    return nce_fwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, 0, temperature, normalize, logits,
-                        row_loss, lse, q_inv, k_inv, dq_unit, stream);
+    return nce_fwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, hard_ld, inb_flags, 0, temperature,
+                        normalize, logits, row_loss, lse, q_inv, k_inv, dq_unit, stream);
 }
 
 extern "C" int hmx_nce_fwd_periodic_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
                                         int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, int64_t period,
-                                        const int64_t* inb_idx, int64_t n_inb, float temperature, int normalize,
-                                        float* logits, float* row_loss, float* lse, float* q_inv, float* k_inv,
-                                        float* dq_unit, void* stream) {
+                                        const void* inb_idx, int64_t n_inb, int64_t hard_ld, int64_t inb_flags,
+                                        float temperature, int normalize, float* logits, float* row_loss, float* lse,
+                                        float* q_inv, float* k_inv, float* dq_unit, void* stream) {
     HMX_ENTER();
     if (period <= 0) return HMX_EINVAL;
-    return nce_fwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, period, temperature, normalize, logits,
-                        row_loss, lse, q_inv, k_inv, dq_unit, stream);
+    return nce_fwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, hard_ld, inb_flags, period, temperature,
+                        normalize, logits, row_loss, lse, q_inv, k_inv, dq_unit, stream);
 }
 
 namespace {
@@ -651,14 +677,16 @@ extern "C" size_t hmx_nce_bwd_grouped_workspace_bytes(int64_t m, int64_t d, int6
 }
 
 static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, const float* table,
-                        int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
-                        int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
+                        int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const void* inb_idx,
+                        int64_t n_inb, int64_t hard_ld, int64_t inb_flags, float temperature, int normalize, float* logits,
+                        const float* lse,
                         const float* q_inv, const float* k_inv, const float* grad_row_loss, const float* dq_unit,
                         float* dq, float* dk, float* dtable, const int64_t* group_start, int64_t n_groups, int64_t period,
                         void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return HMX_OK;
     const bool grouped = group_start != nullptr && n_hard > 0;
     if (grouped && (n_groups <= 0 || period <= 0 || period > kMaxPeriod || period > n_hard)) return HMX_EINVAL;
+    if (!index_args_ok(n_hard, hard_ld, grouped ? period : 0, inb_flags)) return HMX_EINVAL;
     if (!nce_shape_ok(m, d, n_rows, n_hard, n_inb) || !(temperature > 0.f)) return HMX_EINVAL;
     if (!q || !k || !logits || !lse || !q_inv || !k_inv || !grad_row_loss || !dq || !dk || !workspace)
         return HMX_EINVAL;
@@ -670,8 +698,8 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
                                    : hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb)))
         return HMX_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize,
-                              logits, nullptr, const_cast<float*>(lse), const_cast<float*>(q_inv),
+    NceParams p = make_params(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, hard_ld, inb_flags, temperature,
+                              normalize, logits, nullptr, const_cast<float*>(lse), const_cast<float*>(q_inv),
                               const_cast<float*>(k_inv));
     p.grad_row_loss = grad_row_loss;
     p.dq = dq;
@@ -693,7 +721,8 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
     if (hipMemsetAsync(dk, 0, (size_t)m * d * sizeof(float), s) != hipSuccess) return HMX_ELAUNCH;
     if (n_inb > 0) {
         WeightedRows src{q, logits, (int)n_inb, C, (int)(1 + n_hard)};
-        const int rc = sorted_segment_add(src, true, inb_idx, nullptr, 0, m * n_inb, d, dk, m, -1, workspace,
+        const IdSource dst = p.inb32 ? IdSource(p.inb32, n_inb, p.inb_skip_self) : IdSource(p.inb_idx);
+        const int rc = sorted_segment_add(src, true, dst, nullptr, 0, m * n_inb, d, dk, m, -1, workspace,
                                           workspace_bytes, s);
         if (rc != HMX_OK) return rc;
     }
@@ -713,14 +742,14 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
             int64_t* ids = ws.take<int64_t>(n);
             const size_t used = hmx_align_up((size_t)n * d * sizeof(float), 256) + hmx_align_up((size_t)n * sizeof(int64_t), 256);
             hipLaunchKernelGGL(nce_group_rows_kernel, dim3((unsigned)n_groups), dim3(256), 0, s, q, logits, m, C, (int)n_hard,
-                               (int)period, 1, group_start, hard_ids, p.cpr, rows, ids);
+                               p.hard_ld, (int)period, 1, group_start, hard_ids, p.cpr, rows, ids);
             HMX_CHECK_LAUNCH();
             PlainRows src{rows};
-            rc = sorted_segment_add(src, true, ids, nullptr, 0, n, d, dtable, n_rows, -1,
+            rc = sorted_segment_add(src, true, IdSource(ids), nullptr, 0, n, d, dtable, n_rows, -1,
                                     static_cast<char*>(workspace) + used, workspace_bytes - used, s, &skeys, &sentinel);
         } else {
             WeightedRows src{q, logits, (int)n_hard, C, 1};
-            rc = sorted_segment_add(src, true, hard_ids, nullptr, 0, n, d, dtable, n_rows, -1, workspace, workspace_bytes,
+            rc = sorted_segment_add(src, true, IdSource(hard_ids), nullptr, 0, n, d, dtable, n_rows, -1, workspace, workspace_bytes,
                                     s, &skeys, &sentinel);
         }
         if (rc != HMX_OK) return rc;
@@ -736,27 +765,30 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
 }
 
 extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
-                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
-                               int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
+                               int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const void* inb_idx,
+                               int64_t n_inb, int64_t hard_ld, int64_t inb_flags, float temperature, int normalize,
+                               float* logits, const float* lse,
                                const float* q_inv, const float* k_inv, const float* grad_row_loss,
                                const float* dq_unit, float* dq, float* dk, float* dtable, void* workspace,
                                size_t workspace_bytes, void* stream) {
     HMX_ENTER();
-    return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize, logits, lse,
-                        q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, nullptr, 0, 0, workspace, workspace_bytes,
-                        stream);
+    if (hard_ld > 0 && hard_ld != n_hard) return HMX_EINVAL;     // every hard slot is read here
+    return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, hard_ld, inb_flags, temperature,
+                        normalize, logits, lse, q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, nullptr, 0, 0, workspace,
+                        workspace_bytes, stream);
 }
 
 extern "C" int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
-                                       int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx,
-                                       int64_t n_inb, float temperature, int normalize, float* logits, const float* lse,
+                                       int64_t n_rows, const int64_t* hard_ids, int64_t n_hard, const void* inb_idx,
+                                       int64_t n_inb, int64_t hard_ld, int64_t inb_flags, float temperature, int normalize,
+                                       float* logits, const float* lse,
                                        const float* q_inv, const float* k_inv, const float* grad_row_loss,
                                        const float* dq_unit, float* dq, float* dk, float* dtable,
                                        const int64_t* group_start, int64_t n_groups, int64_t period, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     HMX_ENTER();
     if (n_hard > 0 && !group_start) return HMX_EINVAL;
-    return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, temperature, normalize, logits, lse,
-                        q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, group_start, n_groups, period, workspace,
-                        workspace_bytes, stream);
+    return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, hard_ld, inb_flags, temperature,
+                        normalize, logits, lse, q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, group_start, n_groups,
+                        period, workspace, workspace_bytes, stream);
 }

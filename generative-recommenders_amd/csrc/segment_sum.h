@@ -76,18 +76,36 @@ inline int lpr_log2_for(int64_t cpr) {
     return l;
 }
 
+// Where the destination row of entry e comes from: an int64 array (torch.long ids), or an int32 array; with
+// skip_self the int32 values are draws r in [0, rows - 1) of entry e's own row i = e / per_row, standing for the row
+// r + (r >= i), i.e. a uniform draw over the rows other than i (hydra3.py:817-830) that was never written out.
+struct IdSource {
+    const int64_t* i64;
+    const int32_t* i32;
+    uint32_t per_row;
+    int skip_self;
+    IdSource(const int64_t* ids) : i64(ids), i32(nullptr), per_row(1), skip_self(0) {}
+    IdSource(const int32_t* ids, int64_t per_row_, int skip) : i64(nullptr), i32(ids), per_row((uint32_t)per_row_), skip_self(skip) {}
+    __device__ __forceinline__ int64_t at(int64_t e) const {
+        if (i64 != nullptr) return i64[e];
+        int64_t r = i32[e];
+        if (skip_self) r += (r >= (int64_t)((uint32_t)e / per_row)) ? 1 : 0;     // e < 2^32 (checked by the sort)
+        return r;
+    }
+};
+
 // ---------------------------------------------------------------- scatter-add ----------
 // Steps 1 and 2: sort key = row id (or `sentinel` for entries that must not contribute), value = Src::make_val(i);
 // the first pass of the sort reads them through this functor.
 template <class Src>
 struct EntriesFromIds {
     Src src;
-    const int64_t* ids;
+    IdSource ids;
     const int64_t* token_type;
     int64_t want_type, n_rows, padding_idx;
     uint32_t sentinel;
     __device__ __forceinline__ uint32_t key(int64_t i) const {
-        const int64_t id = ids[i];
+        const int64_t id = ids.at(i);
         bool ok = id >= 0 && id < n_rows && id != padding_idx;
         if (token_type != nullptr) ok = ok && token_type[i] == want_type;
         return ok ? (uint32_t)id : sentinel;
@@ -552,7 +570,7 @@ inline size_t workspace_bytes(int64_t n, int64_t n_rows, int64_t d) {
 // sorted_keys_out (optional) receives the device pointer of the sorted keys inside the workspace (n entries,
 // `sentinel_out` marks entries that did not contribute; they sort last).
 template <class Src>
-int sorted_segment_add(const Src& src, bool vec, const int64_t* ids, const int64_t* token_type, int64_t want_type,
+int sorted_segment_add(const Src& src, bool vec, const IdSource& ids, const int64_t* token_type, int64_t want_type,
                        int64_t n, int64_t d, float* table, int64_t n_rows, int64_t padding_idx, void* workspace,
                        size_t ws_bytes, hipStream_t s, const uint32_t** sorted_keys_out = nullptr,
                        uint32_t* sentinel_out = nullptr) {

@@ -57,6 +57,7 @@ struct CoarseParams {
     uint2* cand;              // [wave][g][lane][CAP] (score bits, local row)
     int* meta_cnt;            // [wave][g][lane]
     float* meta_thr;          // [wave][g][lane]
+    const int32_t* only_flagged;   // (n_q) or null.  Non-null: query tiles without a flagged query do nothing  [fp32 pass]
 };
 
 __device__ __forceinline__ void decode_wave(const CoarseParams& p, int& qtile, int& split) {
@@ -682,6 +683,10 @@ __global__ __launch_bounds__(64, 2) void coarse_f32_kernel(CoarseParams p) {
     const int64_t row_end = min(row_begin + p.rows_per_split, p.n_rows);
     uint2* wave_buf = p.cand + wave * 64 * CAP;
     const int64_t q_global = (int64_t)qtile * 32 + j;
+    if (p.only_flagged != nullptr) {    // wave-uniform: nothing to redo in this tile (the re-score skips its queries too)
+        const bool f = q_global < p.n_q && p.only_flagged[q_global] != 0;
+        if (__ballot(f) == 0ull) return;
+    }
     const float* qrow = p.q_f32 + min(q_global, p.n_q - 1) * p.d;
     float thr = kNegInf;
     int cnt = 0;
@@ -724,6 +729,7 @@ struct RescoreParams {
     float* out_scores;
     int32_t* uncertain;         // (n_q) or null
     const int* ring_error;      // non-null: a set flag marks every query of the launch uncertain
+    const int32_t* only_flagged;   // (n_q) or null.  Non-null: only queries with a non-zero flag are selected and written
     float* bound_out;           // (n_q) or null.  Non-null: the completeness decision is left to the caller (lists of
                                 // several item ranges are merged first): bound_out[q] = the score below which rows of
                                 // this range may have been dropped (largest lane threshold + coarse error margin, -inf
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p)
     __shared__ unsigned sh_i[2][4];
     const int t = threadIdx.x % TPQ;
     const int64_t q = (int64_t)blockIdx.x * QPB + threadIdx.x / TPQ;
-    const bool q_ok = q < p.n_q;
+    const bool q_ok = q < p.n_q && (p.only_flagged == nullptr || p.only_flagged[q] != 0);
     const int CAP = p.cap;
     const int n_cand = p.n_splits * 2 * p.KP;
     const int qtile = (int)(q / (32 * p.NB)), g = (int)((q / 32) % p.NB), jq = (int)(q % 32);
@@ -1407,7 +1413,8 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
              const float* max_row_norm, int64_t n_rows, int64_t d, int64_t k, const int64_t* exclude, int64_t n_excl,
              int64_t id_offset, int64_t* out_ids, float* out_scores, int32_t* uncertain, void* workspace,
              size_t workspace_bytes, hipStream_t s, const float* ext_thr = nullptr, float* bound_out = nullptr,
-             float* sample_out = nullptr, int64_t sample_ranges = 1, int sample_values = 1) {
+             float* sample_out = nullptr, int64_t sample_ranges = 1, int sample_values = 1,
+             const int32_t* only_flagged = nullptr) {
     // ext_thr (n_q): start thresholds supplied by the caller (used in place of the sampled ones); bound_out (n_q):
     // see RescoreParams; sample_out (n_q, sample_values): only the sampled start thresholds are computed and written
     // (-inf where this launch shape does not sample), no scoring pass runs.  sample_values = 1: the threshold itself;
@@ -1470,6 +1477,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             p.cand = cand;
             p.meta_cnt = meta_cnt;
             p.meta_thr = meta_thr;
+            p.only_flagged = (!bf16 && only_flagged != nullptr) ? only_flagged + q0 : nullptr;
             void* span = hmx_profile_begin(tag, s);
             if (bf16) {
                 if (plan.NB == 4) launch_bf16_ks<4>(p, plan.KS, plan.KP, s);
@@ -1506,6 +1514,7 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             r.out_ids = out_ids + q0 * k;
             r.out_scores = out_scores + q0 * k;
             r.uncertain = flags;
+            r.only_flagged = (!bf16 && only_flagged != nullptr) ? only_flagged + q0 : nullptr;
             r.bound_out = (bound_out != nullptr && rows == n_rows) ? bound_out + q0 : nullptr;
             r.ring_error = (ring && ring_pass(plan.NB, plan.KS, rows)) ? ring_error : nullptr;
             launch_rescore(r, s);
@@ -1619,6 +1628,17 @@ extern "C" int hmx_score_topk_f32(const float* queries, int64_t n_q, const float
     HMX_ENTER();
     return run_topk(false, queries, n_q, table, nullptr, nullptr, n_rows, d, k, exclude, n_excl, id_offset, out_ids,
                     out_scores, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int hmx_score_topk_f32_flagged(const float* queries, int64_t n_q, const float* table, int64_t n_rows, int64_t d,
+                                          int64_t k, const int64_t* exclude, int64_t n_excl, int64_t id_offset,
+                                          const int32_t* flags, int64_t* out_ids, float* out_scores, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    HMX_ENTER();
+    if (!flags && n_q > 0) return HMX_EINVAL;
+    return run_topk(false, queries, n_q, table, nullptr, nullptr, n_rows, d, k, exclude, n_excl, id_offset, out_ids,
+                    out_scores, nullptr, workspace, workspace_bytes, (hipStream_t)stream, nullptr, nullptr, nullptr, 1, 1,
+                    flags);
 }
 
 extern "C" int hmx_score_topk_bf16(const float* queries, int64_t n_q, const float* table, const uint16_t* table_bf16,

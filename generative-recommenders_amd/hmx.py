@@ -55,6 +55,7 @@ PROTOTYPES = {
     "hmx_table_prepare_bf16": (c_int, [P, I64, I64, P, P, P]),
     "hmx_score_topk_workspace_bytes": (c_size_t, [I64, I64, I64, I64]),
     "hmx_score_topk_f32": (c_int, [P, I64, P, I64, I64, I64, P, I64, I64, P, P, P, c_size_t, P]),
+    "hmx_score_topk_f32_flagged": (c_int, [P, I64, P, I64, I64, I64, P, I64, I64, P, P, P, P, c_size_t, P]),
     "hmx_score_topk_bf16": (c_int, [P, I64, P, P, P, I64, I64, I64, P, I64, I64, P, P, P, P, c_size_t, P]),
     "hmx_topk_sample_thresholds_bf16": (c_int, [P, I64, P, I64, I64, I64, I64, I64, P, P, c_size_t, P]),
     "hmx_kth_largest_f32": (c_int, [P, I64, I64, I64, I64, I64, P, P]),
@@ -65,14 +66,15 @@ PROTOTYPES = {
     "hmx_attn1q_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, P, P, P]),
     "hmx_pscan_fwd": (c_int, [P, P, I64, I64, I64, P, P]),
     "hmx_pscan_bwd": (c_int, [P, P, P, I64, I64, I64, P, P, P]),
-    "hmx_nce_fwd_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, F, c_int, P, P, P, P, P, P, P]),
+    "hmx_nce_fwd_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P, P, P]),
     "hmx_nce_bwd_workspace_bytes": (c_size_t, [I64, I64, I64, I64, I64]),
-    "hmx_nce_bwd_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, F, c_int, P, P, P, P, P, P, P, P, P, P,
+    "hmx_nce_bwd_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P, P, P, P, P, P,
                                 c_size_t, P]),
-    "hmx_nce_fwd_periodic_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, I64, P, I64, F, c_int, P, P, P, P, P, P, P]),
+    "hmx_nce_fwd_periodic_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P,
+                                         P, P]),
     "hmx_nce_bwd_grouped_workspace_bytes": (c_size_t, [I64, I64, I64, I64, I64, I64, I64]),
-    "hmx_nce_bwd_grouped_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, F, c_int, P, P, P, P, P, P, P, P, P, P,
-                                        I64, I64, P, c_size_t, P]),
+    "hmx_nce_bwd_grouped_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P, P, P, P,
+                                        P, P, I64, I64, P, c_size_t, P]),
     "hmx_adamw_chunk_elems": (I64, []),
     "hmx_grad_norm_workspace_bytes": (c_size_t, [I64]),
     "hmx_grad_norm_f32": (c_int, [P, P, I64, I64, F, P, c_size_t, P, P]),

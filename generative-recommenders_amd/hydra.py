@@ -334,9 +334,50 @@ class _TakeRows(torch.autograd.Function):
         return dx, None
 
 
+class LossRows:
+    """The positions of a (B, L) loss mask, found on the HOST: the row numbers (row-major), the sequence of each row
+    and the first row of each sequence, uploaded together.  Boolean indexing / nonzero() on the device would make
+    the host wait for the whole encoder before it can size the loss tensors; here a mask that lives on the device is
+    copied to pinned host memory when this object is made (Hydra.forward makes it before the encoder runs) and only
+    that small copy is waited for when the rows are needed.  main.py keeps next_token_type on the host, in which case
+    nothing is copied at all."""
+
+    def __init__(self, mask, device):
+        self.device = torch.device(device)
+        self.shape = tuple(mask.shape)
+        self._event = None
+        self._ready = None
+        mask = mask.bool()
+        if mask.is_cuda:
+            self._host = torch.empty(mask.shape, dtype=torch.bool, pin_memory=True)
+            self._host.copy_(mask, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._host = mask
+
+    def get(self):
+        """-> (rows (M,), seq_of_row (M,), starts (B + 1,)) int64 on the device, M."""
+        if self._ready is None:
+            if self._event is not None:
+                self._event.synchronize()
+            import numpy as np
+            m = self._host.numpy()
+            B, L = m.shape
+            rows = np.flatnonzero(m)
+            starts = np.zeros(B + 1, dtype=np.int64)
+            np.cumsum(m.sum(1), out=starts[1:])
+            M = int(rows.shape[0])
+            packed = torch.from_numpy(np.concatenate([rows, rows // L, starts]))
+            if self.device.type == "cuda":
+                packed = packed.pin_memory().to(self.device, non_blocking=True)
+            self._ready = (packed[:M], packed[M:2 * M], packed[2 * M:], M)
+        return self._ready
+
+
 def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=None, hard_negatives=None, T=512,
                                    hard_ratio=0.3, temperature=0.05, normalize=True, q_chunk=64, device=None,
-                                   predrawn=None):
+                                   predrawn=None, loss_rows=None):
     """hydra3.py:845-974 (InfoNCE over in-batch + hard negatives).  The negatives are drawn here exactly as the
     reference draws them (index tensors only); the loss itself -- hard-negative row gather, normalisation, the
     (M, 513) logits, log-softmax and the whole backward incl. the scatter into the item-table gradient -- is one
@@ -344,16 +385,17 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
     no effect on the value; it is accepted and ignored.
     predrawn = (hard_ids (M, n) item-table rows or None, inb_idx (M, n') rows of the masked positives or None)
     replaces the sampling: the loss is then a deterministic function of its inputs (used to compare a whole train
-    step with draws recorded from the reference, whose CPU generator a GPU cannot replay)."""
+    step with draws recorded from the reference, whose CPU generator a GPU cannot replay).
+    loss_rows: a LossRows made earlier from the same mask (Hydra.forward does, so that its host copy is long done)."""
     device = log_feats.device
-    mask = loss_mask.bool()
-    # the masked positions in row-major order, found once (boolean indexing would search the mask per tensor)
-    rows = mask.reshape(-1).nonzero().flatten()
+    if loss_rows is None:
+        loss_rows = LossRows(loss_mask, device)
+    # the masked positions in row-major order, found once on the host
+    rows, seq_of_row, starts, M = loss_rows.get()
     d = log_feats.shape[-1]
-    q, k = _TakeRows.apply(log_feats.reshape(-1, d), rows), _TakeRows.apply(pos_embs.reshape(-1, d), rows)
-    M = q.shape[0]
     if M == 0:
         return torch.tensor(0.0, device=device, requires_grad=True)
+    q, k = _TakeRows.apply(log_feats.reshape(-1, d), rows), _TakeRows.apply(pos_embs.reshape(-1, d), rows)
     if predrawn is not None:
         hard_ids, inb = predrawn
         return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize).mean()
@@ -361,51 +403,59 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
     num_inb = T - num_hard
     hard_ids = None
     hard_groups = None
+    n_hard_slots = None
     if hard_negatives is not None and num_hard > 0:                      # hydra3.py:905-919
-        if hard_negatives.stride(1) == 0:         # one list per sequence, broadcast over its positions
-            ch = hard_negatives[:, 0].index_select(0, torch.div(rows, mask.shape[1], rounding_mode="floor"))
+        per_sequence = hard_negatives.dim() == 3 and hard_negatives.stride(1) == 0
+        if per_sequence:                          # one list per sequence, broadcast over its positions
+            ch = hard_negatives[:, 0].index_select(0, seq_of_row)
         else:
             ch = hard_negatives.reshape(-1, hard_negatives.shape[-1]).index_select(0, rows)
         K = ch.shape[1]
         if K >= num_hard:
             ch = torch.gather(ch, 1, torch.randint(0, K, (M, num_hard), device=device))
+        elif per_sequence and K <= 64 and q.is_cuda:
+            # Fewer ids than slots: the reference tiles them over the slots (hydra3.py:911-914).  The rows of a
+            # sequence are consecutive in the masked order and share their list, so the tiled copy is not built: the
+            # loss takes the (M, K) lists, the number of slots they stand for and where each sequence's rows start.
+            # Contract of this path: hard_negatives is ONE (B, K) list per sequence broadcast over the positions
+            # (stride(1) == 0 says exactly that for the tensor as it arrives); ids that differ between the positions
+            # of a sequence must come as a dense (B, L, K) tensor.  VALIDATE_HARD_GROUPS re-checks it on the device.
+            hard_groups = (starts, K)
+            n_hard_slots = num_hard
+            if VALIDATE_HARD_GROUPS:
+                first = ch.index_select(0, starts[:-1].clamp(max=M - 1).index_select(0, seq_of_row))
+                if not torch.equal(ch, first):
+                    raise hmx.HmxError("hard negatives are not one list per sequence: pass a dense (B, L, K) tensor "
+                                       "instead of a broadcast view")
         else:
             ch = ch.repeat(1, (num_hard + K - 1) // K)[:, :num_hard]
-            # one list per user, broadcast over its positions (Hydra.forward): the rows of a user are consecutive in
-            # the masked order and share their ids, which the loss backward can use
-            # Contract of the grouped path: hard_negatives is ONE (B, K) list per sequence broadcast over the positions
-            # (stride(1) == 0 says exactly that for the tensor as it arrives); hard ids that differ between the
-            # positions of a sequence must come as a dense (B, L, K) tensor.  VALIDATE_HARD_GROUPS re-checks it on
-            # the device (one comparison + a host sync per call).
-            if hard_negatives.dim() == 3 and hard_negatives.stride(1) == 0 and K <= 64 and q.is_cuda:
-                starts = torch.zeros(mask.shape[0] + 1, dtype=torch.int64, device=device)
-                starts[1:] = mask.sum(1).cumsum(0)
-                hard_groups = (starts, K)
-                if VALIDATE_HARD_GROUPS:
-                    seq_of_row = torch.div(rows, mask.shape[1], rounding_mode="floor")
-                    first = ch.index_select(0, starts[:-1].clamp(max=max(M - 1, 0)).index_select(0, seq_of_row))
-                    period_ok = torch.equal(ch, ch[:, :K].repeat(1, (num_hard + K - 1) // K)[:, :num_hard])
-                    if not (period_ok and torch.equal(ch, first)):
-                        raise hmx.HmxError("hard negatives are not one periodic list per sequence: pass a dense "
-                                           "(B, L, K) tensor instead of a broadcast view")
         hard_ids = ch
     inb = None
+    skip_self = False
     if num_inb > 0:                                                      # hydra3.py:921-950
-        rows = torch.arange(M, device=device)
-        if M - 1 >= num_inb:
-            inb = _sample_inbatch_indices_no_self(M, rows, num_inb, device)
+        if M - 1 >= num_inb and M - 1 < 2 ** 31 and q.is_cuda:
+            # hydra3.py:824-829: r uniform in [0, M - 1), index r + (r >= own row).  Only r is drawn (32-bit: the
+            # generator yields the same values for either width); the loss kernels apply the shift as they read it
+            inb = torch.randint(0, M - 1, (M, num_inb), device=device, dtype=torch.int32)
+            skip_self = True
+        elif M - 1 >= num_inb:
+            inb = _sample_inbatch_indices_no_self(M, torch.arange(M, device=device), num_inb, device)
         else:
-            base = rows.unsqueeze(0).repeat(M, 1)
-            inb = base[base != rows.unsqueeze(1)].view(M, M - 1)
+            ar = torch.arange(M, device=device)
+            base = ar.unsqueeze(0).repeat(M, 1)
+            inb = base[base != ar.unsqueeze(1)].view(M, M - 1)
             short = num_inb - (M - 1)
             if short > 0:
                 if item_table is not None:       # random table rows fill the batch's shortfall: more table keys
                     rid = torch.randint(1, item_table.shape[0], (M, short), device=device)
+                    if hard_groups is not None:  # the extra random rows break the per-sequence repetition
+                        hard_ids = hard_ids.repeat(1, (num_hard + hard_ids.shape[1] - 1) // hard_ids.shape[1])[:, :num_hard]
+                        hard_groups, n_hard_slots = None, None
                     hard_ids = rid if hard_ids is None else torch.cat([hard_ids, rid], dim=1)
-                    hard_groups = None            # the extra random rows break the per-user repetition
                 else:
                     inb = torch.cat([inb, inb[:, -1:].expand(-1, short)], dim=1)
-    return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize, hard_groups=hard_groups).mean()
+    return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize, hard_groups=hard_groups,
+                              n_hard=n_hard_slots, inb_skip_self=skip_self).mean()
 
 
 class EnhancedTrainingLoss(nn.Module):
@@ -420,14 +470,15 @@ class EnhancedTrainingLoss(nn.Module):
         self.q_chunk = getattr(args, 'loss_q_chunk', 256)          # hydra3.py:1132
         self.adaptive_hard_sampler = AdaptiveHardNegativeSampler()
 
-    def forward(self, user_embs, pos_embs, neg_embs, hard_negatives, loss_mask, item_table, predrawn=None):
+    def forward(self, user_embs, pos_embs, neg_embs, hard_negatives, loss_mask, item_table, predrawn=None,
+                loss_rows=None):
         total = self.contrastive_loss_weight * compute_mixed_contrastive_loss(
             user_embs, pos_embs, loss_mask, item_table, hard_negatives, hard_ratio=0.3, T=512, temperature=0.05,
-            q_chunk=self.q_chunk, predrawn=predrawn)
+            q_chunk=self.q_chunk, predrawn=predrawn, loss_rows=loss_rows)
         self.adaptive_hard_sampler.update_step()
         if neg_embs is not None and self.ranking_loss_weight != 0.0:
             total = total + self.ranking_loss_weight * self.compute_ranking_loss(
-                user_embs[:, -1], pos_embs[:, -1], neg_embs[:, -1], loss_mask[:, -1])
+                user_embs[:, -1], pos_embs[:, -1], neg_embs[:, -1], loss_mask[:, -1].to(user_embs.device))
         if self.diversity_loss_weight != 0.0:
             total = total + self.diversity_loss_weight * self.compute_diversity_loss(user_embs[:, -1], item_table)
         return total
@@ -576,6 +627,9 @@ class Hydra(nn.Module):
         predrawn: see compute_mixed_contrastive_loss.  The mined hard-negative ids of the call are kept in
         self.last_mined_ids."""
         E.discard_stale_wgrads()
+        # the loss positions are found on the host; a mask that lives on the device starts its way there now
+        loss_mask = next_mask == 1                # main.py leaves next_mask on the host (hydra3.py:688)
+        loss_rows = LossRows(loss_mask, user_item.device)
         log_feats = self.log2feats(user_item, seq_feature, mask, timestamp, action_type, dwell_bins)
         se = self.shared_embeddings
         item_table = se.item_emb.weight
@@ -586,14 +640,14 @@ class Hydra(nn.Module):
         if self.enchanced_loss.ranking_loss_weight != 0.0:
             neg_embs = self._project_ids(*se.embedding_parts(neg_seqs.reshape(B * L), neg_feature, None, False,
                                                              'early')).view(B, L, -1)
+        loss_rows.get()      # host-side work, done while the device still has the encoder queued
         miner = HardNegativeMiner(self, item_table, top_k=50, prepared=self.prepared_item_table())
         hard = miner.mine_hard_negatives_similarity(log_feats[:, -1, :], positive_items=pos_seqs,
                                                     exclude_items=user_item)
         self.last_mined_ids = hard
         hard = hard.unsqueeze(1).expand(-1, log_feats.shape[1], -1)
         return self.enchanced_loss(user_embs=log_feats, pos_embs=pos_embs, neg_embs=neg_embs, hard_negatives=hard,
-                                   loss_mask=(next_mask == 1).to(log_feats.device), item_table=item_table,
-                                   predrawn=predrawn)     # main.py leaves next_mask on the host (hydra3.py:688)
+                                   loss_mask=loss_mask, item_table=item_table, predrawn=predrawn, loss_rows=loss_rows)
 
 
 IDS_ONLY_FEAT_TYPES = {k: [] for k in ('user_sparse', 'item_sparse', 'user_array', 'item_array',

@@ -181,16 +181,25 @@ FUSE_NCE_QUERY_GRAD = True    # the forward's key walk also accumulates d loss /
 
 class _FusedNCE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, table, hard_ids, inb_idx, temperature, normalize, hard_groups):
+    def forward(ctx, q, k, table, hard_ids, inb_idx, temperature, normalize, hard_groups, n_hard, inb_skip_self):
         _need_cuda(q, k, table, hard_ids, inb_idx)
         q, k = _f32c(q), _f32c(k)
         m, d = q.shape
         assert k.shape == (m, d)
-        n_hard = 0 if hard_ids is None else hard_ids.shape[1]
+        hard_ld = 0 if hard_ids is None else hard_ids.shape[1]
+        n_hard = hard_ld if n_hard is None else int(n_hard)
         n_inb = 0 if inb_idx is None else inb_idx.shape[1]
         tab = _f32c(table.detach()) if (table is not None and n_hard > 0) else None
         hid = _i64c(hard_ids) if n_hard > 0 else None
-        iid = _i64c(inb_idx) if n_inb > 0 else None
+        flags = 0
+        iid = None
+        if n_inb > 0:
+            if inb_idx.dtype == torch.int32:
+                iid, flags = inb_idx.contiguous(), 1 | (2 if inb_skip_self else 0)
+            else:
+                if inb_skip_self:
+                    raise hmx.HmxError("fused_nce_rows: inb_skip_self needs int32 draws")
+                iid = _i64c(inb_idx)
         dev = q.device
         logits = torch.empty(m, 1 + n_hard + n_inb, dtype=torch.float32, device=dev)
         row_loss, lse, q_inv, k_inv = (torch.empty(m, dtype=torch.float32, device=dev) for _ in range(4))
@@ -202,22 +211,25 @@ class _FusedNCE(torch.autograd.Function):
             gs, period = hard_groups
             gs = _i64c(gs)
             _need_cuda(gs)
-            if not (1 <= int(period) <= min(64, n_hard)) or gs.numel() < 2:
-                raise hmx.HmxError("fused_nce_rows: hard_groups needs 1 <= period <= min(64, n_hard) and >= 1 group")
+            if not (1 <= int(period) <= min(64, n_hard, hard_ld)) or gs.numel() < 2:
+                raise hmx.HmxError("fused_nce_rows: hard_groups needs 1 <= period <= min(64, n_hard, row length) and >= 1 group")
             groups = (gs, int(period))
+        elif n_hard != hard_ld:
+            raise hmx.HmxError("fused_nce_rows: hard_ids rows shorter than n_hard need hard_groups (repeating slots)")
         if groups is not None:
             hmx.check(hmx.lib().hmx_nce_fwd_periodic_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid),
-                                                         n_hard, groups[1], hmx.ptr(iid), n_inb, float(temperature),
-                                                         int(bool(normalize)), hmx.ptr(logits), hmx.ptr(row_loss),
-                                                         hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(dq_unit),
-                                                         hmx.current_stream()), "hmx_nce_fwd_periodic_f32")
+                                                         n_hard, groups[1], hmx.ptr(iid), n_inb, hard_ld, flags,
+                                                         float(temperature), int(bool(normalize)), hmx.ptr(logits),
+                                                         hmx.ptr(row_loss), hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv),
+                                                         hmx.ptr(dq_unit), hmx.current_stream()), "hmx_nce_fwd_periodic_f32")
         else:
             hmx.check(hmx.lib().hmx_nce_fwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
-                                                hmx.ptr(iid), n_inb, float(temperature), int(bool(normalize)),
-                                                hmx.ptr(logits), hmx.ptr(row_loss), hmx.ptr(lse), hmx.ptr(q_inv),
-                                                hmx.ptr(k_inv), hmx.ptr(dq_unit), hmx.current_stream()), "hmx_nce_fwd_f32")
+                                                hmx.ptr(iid), n_inb, hard_ld, flags, float(temperature),
+                                                int(bool(normalize)), hmx.ptr(logits), hmx.ptr(row_loss), hmx.ptr(lse),
+                                                hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(dq_unit), hmx.current_stream()),
+                      "hmx_nce_fwd_f32")
         ctx.save_for_backward(q, k, tab, hid, iid, logits, lse, q_inv, k_inv, dq_unit)
-        ctx.cfg = (float(temperature), int(bool(normalize)), n_rows, n_hard, n_inb)
+        ctx.cfg = (float(temperature), int(bool(normalize)), n_rows, n_hard, n_inb, hard_ld, flags)
         ctx.table_param = table
         ctx.groups = groups
         return row_loss
@@ -225,7 +237,7 @@ class _FusedNCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_rows):
         q, k, tab, hid, iid, logits, lse, q_inv, k_inv, dq_unit = ctx.saved_tensors
-        temperature, normalize, n_rows, n_hard, n_inb = ctx.cfg
+        temperature, normalize, n_rows, n_hard, n_inb, hard_ld, flags = ctx.cfg
         m, d = q.shape
         dev = q.device
         g = _f32c(grad_rows)
@@ -248,28 +260,33 @@ class _FusedNCE(torch.autograd.Function):
             ng = gs.numel() - 1
             ws = workspace(L.hmx_nce_bwd_grouped_workspace_bytes(m, d, n_rows, n_hard, n_inb, ng, period), dev)
             hmx.check(L.hmx_nce_bwd_grouped_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
-                                                hmx.ptr(iid), n_inb, temperature, normalize, hmx.ptr(coef), hmx.ptr(lse),
-                                                hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq_unit), hmx.ptr(dq),
-                                                hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(gs), ng, period, hmx.ptr(ws), ws.numel(),
-                                                hmx.current_stream()), "hmx_nce_bwd_grouped_f32")
+                                                hmx.ptr(iid), n_inb, hard_ld, flags, temperature, normalize, hmx.ptr(coef),
+                                                hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq_unit),
+                                                hmx.ptr(dq), hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(gs), ng, period,
+                                                hmx.ptr(ws), ws.numel(), hmx.current_stream()), "hmx_nce_bwd_grouped_f32")
         else:
             ws = workspace(L.hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb), dev)
             hmx.check(L.hmx_nce_bwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
-                                        hmx.ptr(iid), n_inb, temperature, normalize, hmx.ptr(coef), hmx.ptr(lse),
-                                        hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq_unit), hmx.ptr(dq),
-                                        hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
-                      "hmx_nce_bwd_f32")
-        return dq, dk, (dtable if (want_table and fused_dst is None) else None), None, None, None, None, None
+                                        hmx.ptr(iid), n_inb, hard_ld, flags, temperature, normalize, hmx.ptr(coef),
+                                        hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq_unit),
+                                        hmx.ptr(dq), hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(ws), ws.numel(),
+                                        hmx.current_stream()), "hmx_nce_bwd_f32")
+        return (dq, dk, (dtable if (want_table and fused_dst is None) else None), None, None, None, None, None, None,
+                None)
 
 
-def fused_nce_rows(q, k, table, hard_ids, inb_idx, temperature=0.05, normalize=True, hard_groups=None):
+def fused_nce_rows(q, k, table, hard_ids, inb_idx, temperature=0.05, normalize=True, hard_groups=None, n_hard=None,
+                   inb_skip_self=False):
     """Per-row InfoNCE loss over [positive k_i | table[hard_ids[i]] | k[inb_idx[i]]] (hydra3.py:845-974 with the
     sampling done by the caller).  q, k: (M, d); hard_ids: (M, n_hard) item-table rows or None; inb_idx:
-    (M, n_inb) rows of k or None.  Gradients flow to q, k and table.  backward() may run once.
+    (M, n_inb) rows of k (int64 or int32) or None.  Gradients flow to q, k and table.  backward() may run once.
     hard_groups = (group_start (G + 1,) int64 offsets into the M rows, period): the caller's promise that inside each
     group of consecutive rows hard_ids[i, s] == hard_ids[first row of the group, s % period] (the reference's tiling
-    of each user's mined ids); the table gradient is then built per group instead of per (row, slot) entry."""
-    return _FusedNCE.apply(q, k, table, hard_ids, inb_idx, temperature, normalize, hard_groups)
+    of each user's mined ids); the table gradient is then built per group instead of per (row, slot) entry.  With
+    groups, hard_ids may hold just the first `period` (or more) columns and n_hard says how many slots they stand
+    for, so the tiled copy is never built.
+    inb_skip_self: inb_idx holds int32 draws r in [0, M - 1) and row i's key is row r + (r >= i) (hydra3.py:824-829)."""
+    return _FusedNCE.apply(q, k, table, hard_ids, inb_idx, temperature, normalize, hard_groups, n_hard, inb_skip_self)
 
 
 # --------------------------------------------------------------------------- scoring + top-K
@@ -339,12 +356,17 @@ def score_topk(queries, prepared, k, exclude=None, id_offset=0, return_stats=Fal
                                     t.shape[0], d, k, hmx.ptr(ex), 0 if ex is None else ex.shape[1], id_offset,
                                     hmx.ptr(ids), hmx.ptr(sc), hmx.ptr(unc), hmx.ptr(ws), ws.numel(),
                                     hmx.current_stream()), "hmx_score_topk_bf16")
-    redo = unc.nonzero().flatten()            # host sync: the only one on this path
-    if redo.numel():
-        ids2, sc2 = score_topk_exact(q[redo], t, k, None if ex is None else ex[redo], id_offset)
-        ids[redo], sc[redo] = ids2, sc2
-    if return_stats:
+    if return_stats:                          # the count is wanted on the host: one synchronisation
+        redo = unc.nonzero().flatten()
+        if redo.numel():
+            ids2, sc2 = score_topk_exact(q[redo], t, k, None if ex is None else ex[redo], id_offset)
+            ids[redo], sc[redo] = ids2, sc2
         return ids, sc, {"uncertain": int(redo.numel())}
+    # no host synchronisation: the exact kernels run over the flagged queries only (tiles without one return at once)
+    hmx.check(L.hmx_score_topk_f32_flagged(hmx.ptr(q), nq, hmx.ptr(t), t.shape[0], d, k, hmx.ptr(ex),
+                                           0 if ex is None else ex.shape[1], id_offset, hmx.ptr(unc), hmx.ptr(ids),
+                                           hmx.ptr(sc), hmx.ptr(ws), ws.numel(), hmx.current_stream()),
+              "hmx_score_topk_f32_flagged")
     return ids, sc
 
 

@@ -83,8 +83,11 @@ class HmxAdamW(torch.optim.Optimizer):
                     raise hmx.HmxError("HmxAdamW needs contiguous fp32 gradients on the GPU")
                 host[i] = (pptr[i], gptr[i], st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
             cached["gptr"], cached["pptr"] = gptr, pptr
-            # pageable source: the bytes are staged before the call returns, the device write is stream-ordered
-            cached["desc"].copy_(torch.from_numpy(host.view(np.uint8).copy()))
+            # Through a pinned staging block, asynchronously: a copy from pageable memory would make the host wait for
+            # everything the stream still holds (the whole backward pass), and the next step's launches would start
+            # only then.  The host allocator keeps the block until the copy that reads it has run.
+            staged = torch.from_numpy(host.view(np.uint8).copy()).pin_memory()
+            cached["desc"].copy_(staged, non_blocking=True)
         return cached
 
     def load_state_dict(self, state_dict):

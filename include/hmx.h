@@ -129,6 +129,14 @@ int hmx_score_topk_f32(const float* queries, int64_t n_q, const float* table, in
                        int64_t k, const int64_t* exclude, int64_t n_excl, int64_t id_offset, int64_t* out_ids,
                        float* out_scores, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The exact path for the queries with flags[q] != 0 only (flags: int32 per query on the device, e.g. the `uncertain`
+ * output of hmx_score_topk_bf16): their rows of out_ids / out_scores are overwritten, every other row is left as it
+ * is, and query tiles without a flagged query cost a few instructions.  Lets a caller repair the uncertain queries of
+ * the fast path without reading their count back to the host. */
+int hmx_score_topk_f32_flagged(const float* queries, int64_t n_q, const float* table, int64_t n_rows, int64_t d,
+                               int64_t k, const int64_t* exclude, int64_t n_excl, int64_t id_offset, const int32_t* flags,
+                               int64_t* out_ids, float* out_scores, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fast path: bf16 MFMA coarse pass keeps a per-query shortlist, which is then re-scored
  * exactly (fma chain over the fp32 table) and ordered with the same tie-break.  A query
  * whose shortlist cannot be proven to contain the exact top-K (coarse-pass error bound vs
@@ -203,15 +211,21 @@ int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_
  * ADDS the hard-negative gradient rows into dtable (n_rows, d), which must be zero on entry (the normalisation
  * Jacobian is applied in place to the rows it touched).  `logits` is overwritten.  d % 4 == 0, d <= 256,
  * 16-byte aligned q / k / table / dq / dk / dtable.  Deterministic (sorted-run sums, no float atomics).
- * --------------------------------------------------------------------------------- */
+ * Index arguments.  hard_ids is (m, hard_ld) with hard_ld = 0 meaning n_hard; a shorter row (hard_ld < n_hard) is
+ * allowed where the slots beyond it repeat (the periodic / grouped calls, period <= hard_ld), so the tiled copy of
+ * hydra3.py:911-914 need not exist.  inb_idx is int64 (m, n_inb) unless inb_flags has HMX_NCE_INB_I32 (then int32);
+ * with HMX_NCE_INB_SKIP_SELF as well, the int32 values are the raw draws r of hydra3.py:824 in [0, m - 1) and row i's
+ * key is row r + (r >= i) (hydra3.py:826-829), applied on the fly. */
+#define HMX_NCE_INB_I32 1
+#define HMX_NCE_INB_SKIP_SELF 2
 int hmx_nce_fwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
-                    const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
-                    float temperature, int normalize, float* logits, float* row_loss, float* lse, float* q_inv,
-                    float* k_inv, float* dq_unit, void* stream);
+                    const int64_t* hard_ids, int64_t n_hard, const void* inb_idx, int64_t n_inb, int64_t hard_ld,
+                    int64_t inb_flags, float temperature, int normalize, float* logits, float* row_loss, float* lse,
+                    float* q_inv, float* k_inv, float* dq_unit, void* stream);
 size_t hmx_nce_bwd_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb);
 int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
-                    const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
-                    float temperature, int normalize, float* logits, const float* lse, const float* q_inv,
+                    const int64_t* hard_ids, int64_t n_hard, const void* inb_idx, int64_t n_inb, int64_t hard_ld,
+                    int64_t inb_flags, float temperature, int normalize, float* logits, const float* lse, const float* q_inv,
                     const float* k_inv, const float* grad_row_loss, const float* dq_unit, float* dq, float* dk,
                     float* dtable, void* workspace, size_t workspace_bytes, void* stream);
 /* Hard negatives that repeat, which is how hydra3.py:905-919 builds them (each user's K mined ids, tiled over the n_hard
@@ -226,14 +240,16 @@ int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const 
  * instead of m * n_hard.  dq, dk and the table rows equal hmx_nce_bwd_f32's up to fp32 summation order.
  * period <= 64, period <= n_hard. */
 int hmx_nce_fwd_periodic_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
-                             const int64_t* hard_ids, int64_t n_hard, int64_t period, const int64_t* inb_idx,
-                             int64_t n_inb, float temperature, int normalize, float* logits, float* row_loss, float* lse,
+                             const int64_t* hard_ids, int64_t n_hard, int64_t period, const void* inb_idx,
+                             int64_t n_inb, int64_t hard_ld, int64_t inb_flags, float temperature, int normalize,
+                             float* logits, float* row_loss, float* lse,
                              float* q_inv, float* k_inv, float* dq_unit, void* stream);
 size_t hmx_nce_bwd_grouped_workspace_bytes(int64_t m, int64_t d, int64_t n_rows, int64_t n_hard, int64_t n_inb,
                                            int64_t n_groups, int64_t period);
 int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table, int64_t n_rows,
-                            const int64_t* hard_ids, int64_t n_hard, const int64_t* inb_idx, int64_t n_inb,
-                            float temperature, int normalize, float* logits, const float* lse, const float* q_inv,
+                            const int64_t* hard_ids, int64_t n_hard, const void* inb_idx, int64_t n_inb, int64_t hard_ld,
+                            int64_t inb_flags, float temperature, int normalize, float* logits, const float* lse,
+                            const float* q_inv,
                             const float* k_inv, const float* grad_row_loss, const float* dq_unit, float* dq, float* dk,
                             float* dtable, const int64_t* group_start, int64_t n_groups, int64_t period, void* workspace,
                             size_t workspace_bytes, void* stream);

@@ -46,7 +46,10 @@ def _case(M, d, R, n_hard, n_inb, seed, users=None, zero_rows=False):
     return q, k, table, hard, inb
 
 
-def _check(q, k, table, hard, inb, temperature=0.05, normalize=True, hard_groups=None):
+def _check(q, k, table, hard, inb, temperature=0.05, normalize=True, hard_groups=None, compact=False):
+    """compact: hand the op the short forms of the indices -- hard_ids cut to their first `period` columns with
+    n_hard saying how many slots they stand for, and the in-batch indices as the int32 draws r (index = r + (r >= own
+    row)) -- against the oracle on the full index tensors."""
     from oracle import hydra_oracle as O
     from generative_recommenders_amd import ops
     w = torch.randn(q.shape[0], generator=torch.Generator().manual_seed(1))     # non-uniform upstream gradient
@@ -55,9 +58,16 @@ def _check(q, k, table, hard, inb, temperature=0.05, normalize=True, hard_groups
     (want * w).sum().backward()
     dev = "cuda"
     gq, gk, gt = (t.to(dev).requires_grad_(True) for t in (q, k, table))
+    kw = {}
+    if compact:
+        own = torch.arange(q.shape[0]).unsqueeze(1)
+        assert not bool((inb == own).any())
+        inb = (inb - (inb > own).long()).to(torch.int32)            # back to the draw r in [0, M - 1)
+        kw = dict(n_hard=hard.shape[1], inb_skip_self=True)
+        hard = hard[:, :hard_groups[1]].contiguous()
     got = ops.fused_nce_rows(gq, gk, gt, None if hard is None else hard.to(dev), None if inb is None else inb.to(dev),
                              temperature, normalize,
-                             hard_groups=None if hard_groups is None else (hard_groups[0].to(dev), hard_groups[1]))
+                             hard_groups=None if hard_groups is None else (hard_groups[0].to(dev), hard_groups[1]), **kw)
     (got * w.to(dev)).sum().backward()
     assert torch.allclose(got.detach().cpu(), want.detach(), atol=3e-5, rtol=1e-5), \
         float((got.detach().cpu() - want.detach()).abs().max())
@@ -86,9 +96,10 @@ def test_user_structured_hard_negatives():
     _check(*_case(900, 64, 20000, 153, 359, seed=3, users=12))
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("M,users,d,n_hard,period", [(900, 12, 64, 153, 50), (60, 40, 64, 153, 50), (500, 7, 128, 20, 7),
                                                       (257, 30, 16, 64, 64), (100, 100, 32, 5, 1)])
-def test_grouped_hard_negative_backward(M, users, d, n_hard, period):
+def test_grouped_hard_negative_backward(M, users, d, n_hard, period, compact):
     """The per-user form of the table gradient (hmx_nce_bwd_grouped_f32): rows of a user are consecutive and share
     `period` ids tiled over the n_hard slots; some users have no rows at all.  Same oracle, same tolerances."""
     g = torch.Generator().manual_seed(M + users)
@@ -99,7 +110,24 @@ def test_grouped_hard_negative_backward(M, users, d, n_hard, period):
     hard = per_user[owner].repeat(1, (n_hard + period - 1) // period)[:, :n_hard].contiguous()
     starts = torch.zeros(users + 1, dtype=torch.int64)
     starts[1:] = torch.bincount(owner, minlength=users).cumsum(0)
-    _check(q, k, table, hard, inb, hard_groups=(starts, period))
+    if compact:                                   # the draws exclude a row's own index
+        own = torch.arange(M).unsqueeze(1)
+        inb = torch.where(inb == own, (inb + 1) % M, inb)
+    _check(q, k, table, hard, inb, hard_groups=(starts, period), compact=compact)
+
+
+def test_int32_in_batch_indices_and_argument_checks():
+    """int32 in-batch indices without the self-skipping rule equal the int64 form; short hard rows without groups and
+    self-skipping with int64 indices are refused."""
+    from generative_recommenders_amd import hmx, ops
+    q, k, table, hard, inb = _case(300, 64, 5000, 20, 40, seed=9)
+    a = ops.fused_nce_rows(q.cuda(), k.cuda(), table.cuda(), hard.cuda(), inb.cuda())
+    b = ops.fused_nce_rows(q.cuda(), k.cuda(), table.cuda(), hard.cuda(), inb.to(torch.int32).cuda())
+    assert torch.equal(a, b)
+    with pytest.raises(hmx.HmxError):
+        ops.fused_nce_rows(q.cuda(), k.cuda(), table.cuda(), hard[:, :5].contiguous().cuda(), inb.cuda(), n_hard=20)
+    with pytest.raises(hmx.HmxError):
+        ops.fused_nce_rows(q.cuda(), k.cuda(), table.cuda(), hard.cuda(), inb.cuda(), inb_skip_self=True)
 
 
 def test_no_hard_or_no_inbatch():

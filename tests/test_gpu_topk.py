@@ -93,6 +93,9 @@ def test_adversarial_near_duplicates_fall_back_to_exact():
     ids, sc, st = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), 10, return_stats=True)
     _check(ids, sc, q, t, 10)
     assert st["uncertain"] > 0
+    # the same repair without reading the count back: the exact kernels run on the flagged queries, in place
+    ids2, sc2 = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), 10)
+    assert torch.equal(ids2, ids) and torch.equal(sc2, sc)
 
 
 @pytest.mark.parametrize("d", [64, 128])
@@ -111,6 +114,9 @@ def test_many_query_launch_with_planted_rows_and_near_duplicates(d):
     ids, sc, st = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), 10, return_stats=True)
     _check(ids, sc, q, t, 10)
     assert st["uncertain"] >= 1                               # query 0 at least needs the exact pass
+    assert st["uncertain"] < nq // 4                           # ... and most need none: the flag-driven repair below
+    ids2, sc2 = ops.score_topk(q.to(DEV), ops.PreparedTable(t.to(DEV)), 10)      # leaves unflagged queries alone
+    assert torch.equal(ids2, ids) and torch.equal(sc2, sc)
 
 
 def test_shared_stream_give_up_ends_early_and_is_rerun_exactly():
