@@ -149,7 +149,7 @@ def run_retrieval(args, world, rank):
     retr = ShardedRetriever(shard, id_offset=lo, item_shards=S, exchange_thresholds=not args.no_threshold_exchange)
     for _ in range(args.warmup):
         retr.search(q, k)
-    hmx.profile_enable(True)
+    hmx.profile_enable(True, only="topk_coarse_bf16")      # the roofline kernel alone is bracketed in the timed region
     hmx.profile_collect("topk_coarse_bf16")
     barrier_sync(world)
     t0 = time.perf_counter()

@@ -15,6 +15,7 @@ struct Span {
 };
 std::mutex g_mu;
 bool g_on = false;
+std::string g_only;          // non-empty: only spans with this tag are recorded
 std::vector<Span> g_spans;
 }  // namespace
 
@@ -22,6 +23,7 @@ bool hmx_profile_on() { return g_on; }
 
 void* hmx_profile_begin(const char* tag, hipStream_t s) {
     if (!g_on) return nullptr;
+    if (!g_only.empty() && g_only != tag) return nullptr;
     Span sp{tag, nullptr, nullptr};
     if (hipEventCreate(&sp.start) != hipSuccess || hipEventCreate(&sp.stop) != hipSuccess) return nullptr;
     (void)hipEventRecord(sp.start, s);
@@ -39,6 +41,12 @@ void hmx_profile_end(void* token, hipStream_t s) {
 extern "C" int hmx_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
+    return HMX_OK;
+}
+
+extern "C" int hmx_profile_filter(const char* tag) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_only = tag ? tag : "";
     return HMX_OK;
 }
 

@@ -1,7 +1,8 @@
 // Stable least-significant-digit radix sort of (uint32 key, value) entries for the sorted-run scatter-add.
 //
 // The keys are table row numbers (or a sentinel that sorts last), so only sort_bits(n_rows) bits are significant;
-// they are cut into ceil(bits / 8) digits of equal width.  A pass is: per-tile digit histograms, an exclusive scan
+// they are cut into ceil(bits / 8) digits of equal width -- or, where that saves a whole pass (17 or 18 key bits:
+// two passes instead of three), into digits of up to 9 bits with 512 counters per tile.  A pass is: per-tile digit histograms, an exclusive scan
 // of every digit's row of tile counts, and a scatter that ranks the entries of a tile in index order (wave ballots
 // match equal digits; one LDS counter per wave and digit, no atomics on the ranking path) and moves them through
 // LDS so that neighbouring lanes write neighbouring addresses.  Entries with equal keys therefore keep their
@@ -12,6 +13,7 @@
 // each tile sums the few histograms before it by itself (two launches per pass).
 #pragma once
 #include <cstdint>
+#include <type_traits>
 
 #include "hmx_common.h"
 
@@ -23,6 +25,7 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kIpt = 16;                       // entries per thread
 constexpr int kTile = kThreads * kIpt;         // entries per workgroup
 constexpr int kDigits = 256;                   // counters per tile (digits narrower than 8 bits use a prefix of them)
+constexpr int kWideDigits = 512;               // ... of a pass with 9-bit digits
 constexpr int kSelfPrefixTiles = 64;
 
 struct Passes {
@@ -32,6 +35,7 @@ struct Passes {
 inline Passes plan_passes(int key_bits) {
     Passes p{};
     p.n = (key_bits + 7) / 8;
+    if ((key_bits + 8) / 9 < p.n) p.n = (key_bits + 8) / 9;     // 9-bit digits only where they save a pass
     if (p.n < 1) p.n = 1;
     int at = 0;
     for (int i = 0; i < p.n; ++i) {
@@ -46,7 +50,9 @@ inline Passes plan_passes(int key_bits) {
 
 inline int64_t n_tiles_for(int64_t n) { return hmx_ceil_div(n, kTile); }
 // histogram rows (one per digit, n_tiles counters each) + the digit totals
-inline size_t counter_bytes(int64_t n) { return hmx_align_up(((size_t)kDigits * n_tiles_for(n) + kDigits) * sizeof(uint32_t), 256); }
+inline size_t counter_bytes(int64_t n) {
+    return hmx_align_up(((size_t)kWideDigits * n_tiles_for(n) + kWideDigits) * sizeof(uint32_t), 256);
+}
 
 template <class Val>
 struct FromArrays {
@@ -56,12 +62,13 @@ struct FromArrays {
     __device__ __forceinline__ Val val(int64_t i) const { return vals[i]; }
 };
 
-template <class In>
+template <class In, int ND>
 __global__ __launch_bounds__(kThreads) void radix_hist_kernel(In in, int64_t n, int shift, uint32_t mask, int n_tiles,
                                                               uint32_t* __restrict__ hist) {
-    __shared__ unsigned h[kDigits];
+    __shared__ unsigned h[ND];
     const int tid = threadIdx.x, lane = tid & 63;
-    h[tid] = 0;
+#pragma unroll
+    for (int dg = tid; dg < ND; dg += kThreads) h[dg] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kTile;
 #pragma unroll 4
@@ -80,7 +87,8 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(In in, int64_t n, 
         }
     }
     __syncthreads();
-    hist[(int64_t)tid * n_tiles + blockIdx.x] = h[tid];
+#pragma unroll
+    for (int dg = tid; dg < ND; dg += kThreads) hist[(int64_t)dg * n_tiles + blockIdx.x] = h[dg];
 }
 
 // exclusive prefix sum over the kThreads values of a workgroup; *total receives their sum
@@ -126,21 +134,25 @@ __global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restri
     if (tid == 0) totals[blockIdx.x] = total;
 }
 
-template <class In, class Val>
+template <class In, class Val, int ND>
 __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(In in, int64_t n, int shift, uint32_t mask, int n_tiles,
                                                                  const uint32_t* __restrict__ hist,
                                                                  const uint32_t* __restrict__ totals, int self_prefix,
                                                                  uint32_t* __restrict__ out_keys, Val* __restrict__ out_vals) {
-    __shared__ uint32_t cnt[kWaves][kDigits];   // per wave and digit: running count, then the wave's base inside the digit
-    __shared__ uint32_t lstart[kDigits];        // where the digit starts in the tile's sorted order
-    __shared__ uint32_t goff[kDigits];          // global position of the digit's first entry of this tile, minus lstart
+    constexpr int DPT = ND / kThreads;          // digits per thread in the per-digit steps: thread t owns DPT t .. DPT t + DPT - 1
+    constexpr int NBITS = ND == 256 ? 8 : 9;
+    __shared__ uint32_t cnt[kWaves][ND];        // per wave and digit: running count, then the wave's base inside the digit
+    __shared__ uint32_t lstart[ND];             // where the digit starts in the tile's sorted order
+    __shared__ uint32_t goff[ND];               // global position of the digit's first entry of this tile, minus lstart
     __shared__ uint32_t wave_sums[kWaves];
     __shared__ uint32_t skey[kTile];
     __shared__ Val sval[kTile];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int tile = blockIdx.x;
 #pragma unroll
-    for (int i = 0; i < kWaves; ++i) cnt[i][tid] = 0;
+    for (int i = 0; i < kWaves; ++i)
+#pragma unroll
+        for (int dg = tid; dg < ND; dg += kThreads) cnt[i][dg] = 0;
     __syncthreads();
 
     // wave w owns entries [w * 64 * kIpt, (w + 1) * 64 * kIpt) of the tile, 64 consecutive ones per round
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(In in, int64_t 
         const uint32_t d = valid ? ((key[r] >> shift) & mask) : 0;
         unsigned long long m = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < NBITS; ++b) {
             const unsigned long long bb = __ballot((d >> b) & 1);
             m &= ((d >> b) & 1) ? bb : ~bb;
         }
@@ -176,32 +188,47 @@ __global__ __launch_bounds__(kThreads) void radix_scatter_kernel(In in, int64_t 
     }
     __syncthreads();
 
-    {   // thread d: this tile's count of digit d, the waves' bases inside it, and the digit's global position
-        uint32_t tile_cnt = 0;
+    {   // per digit: this tile's count, the waves' bases inside it, and the digit's global position.  A thread owns
+        // DPT consecutive digits, so the two exclusive scans run over per-thread sums and are refined inside the thread.
+        uint32_t tile_cnt[DPT], before_tiles[DPT], digit_total[DPT];
+        uint32_t my_cnt = 0, my_total = 0;
 #pragma unroll
-        for (int i = 0; i < kWaves; ++i) {
-            const uint32_t c = cnt[i][tid];
-            cnt[i][tid] = tile_cnt;
-            tile_cnt += c;
-        }
-        uint32_t before_tiles, digit_total;
-        if (self_prefix) {
-            before_tiles = 0;
-            digit_total = 0;
-            for (int t = 0; t < n_tiles; ++t) {
-                const uint32_t c = hist[(int64_t)tid * n_tiles + t];
-                if (t < tile) before_tiles += c;
-                digit_total += c;
+        for (int u = 0; u < DPT; ++u) {
+            const int dg = tid * DPT + u;
+            uint32_t tc = 0;
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) {
+                const uint32_t c = cnt[i][dg];
+                cnt[i][dg] = tc;
+                tc += c;
             }
-        } else {
-            before_tiles = hist[(int64_t)tid * n_tiles + tile];
-            digit_total = totals[tid];
+            tile_cnt[u] = tc;
+            if (self_prefix) {
+                before_tiles[u] = 0;
+                digit_total[u] = 0;
+                for (int t = 0; t < n_tiles; ++t) {
+                    const uint32_t c = hist[(int64_t)dg * n_tiles + t];
+                    if (t < tile) before_tiles[u] += c;
+                    digit_total[u] += c;
+                }
+            } else {
+                before_tiles[u] = hist[(int64_t)dg * n_tiles + tile];
+                digit_total[u] = totals[dg];
+            }
+            my_cnt += tile_cnt[u];
+            my_total += digit_total[u];
         }
         uint32_t unused;
-        const uint32_t ls = block_exclusive_scan(tile_cnt, wave_sums, &unused);
-        const uint32_t digit_base = block_exclusive_scan(digit_total, wave_sums, &unused);
-        lstart[tid] = ls;
-        goff[tid] = digit_base + before_tiles - ls;
+        uint32_t ls = block_exclusive_scan(my_cnt, wave_sums, &unused);
+        uint32_t digit_base = block_exclusive_scan(my_total, wave_sums, &unused);
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const int dg = tid * DPT + u;
+            lstart[dg] = ls;
+            goff[dg] = digit_base + before_tiles[u] - ls;
+            ls += tile_cnt[u];
+            digit_base += digit_total[u];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -235,7 +262,7 @@ int sort_entries(const First& first, int64_t n, int key_bits, uint32_t* keys_out
     const Passes pp = plan_passes(key_bits);
     const int n_tiles = (int)n_tiles_for(n);
     uint32_t* hist = counters;
-    uint32_t* totals = counters + (size_t)kDigits * n_tiles;
+    uint32_t* totals = counters + (size_t)kWideDigits * n_tiles;
     const int self_prefix = n_tiles <= kSelfPrefixTiles ? 1 : 0;
     const uint32_t* src_keys = nullptr;
     const Val* src_vals = nullptr;
@@ -244,19 +271,23 @@ int sort_entries(const First& first, int64_t n, int key_bits, uint32_t* keys_out
         uint32_t* dk = to_out ? keys_out : keys_tmp;
         Val* dv = to_out ? vals_out : vals_tmp;
         const uint32_t mask = (1u << pp.bits[p]) - 1u;
-        if (p == 0) {
-            hipLaunchKernelGGL(radix_hist_kernel<First>, dim3(n_tiles), dim3(kThreads), 0, s, first, n, pp.shift[p], mask,
+        auto run_pass = [&](const auto& in, auto nd_tag) {
+            constexpr int ND = decltype(nd_tag)::value;
+            using In = std::decay_t<decltype(in)>;
+            hipLaunchKernelGGL((radix_hist_kernel<In, ND>), dim3(n_tiles), dim3(kThreads), 0, s, in, n, pp.shift[p], mask,
                                n_tiles, hist);
-            if (!self_prefix) hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(kThreads), 0, s, hist, n_tiles, totals);
-            hipLaunchKernelGGL((radix_scatter_kernel<First, Val>), dim3(n_tiles), dim3(kThreads), 0, s, first, n, pp.shift[p],
+            if (!self_prefix) hipLaunchKernelGGL(radix_scan_kernel, dim3(ND), dim3(kThreads), 0, s, hist, n_tiles, totals);
+            hipLaunchKernelGGL((radix_scatter_kernel<In, Val, ND>), dim3(n_tiles), dim3(kThreads), 0, s, in, n, pp.shift[p],
                                mask, n_tiles, hist, totals, self_prefix, dk, dv);
+        };
+        const bool wide = pp.bits[p] > 8;
+        if (p == 0) {
+            if (wide) run_pass(first, std::integral_constant<int, kWideDigits>{});
+            else run_pass(first, std::integral_constant<int, kDigits>{});
         } else {
             const FromArrays<Val> in{src_keys, src_vals};
-            hipLaunchKernelGGL(radix_hist_kernel<FromArrays<Val>>, dim3(n_tiles), dim3(kThreads), 0, s, in, n, pp.shift[p],
-                               mask, n_tiles, hist);
-            if (!self_prefix) hipLaunchKernelGGL(radix_scan_kernel, dim3(kDigits), dim3(kThreads), 0, s, hist, n_tiles, totals);
-            hipLaunchKernelGGL((radix_scatter_kernel<FromArrays<Val>, Val>), dim3(n_tiles), dim3(kThreads), 0, s, in, n,
-                               pp.shift[p], mask, n_tiles, hist, totals, self_prefix, dk, dv);
+            if (wide) run_pass(in, std::integral_constant<int, kWideDigits>{});
+            else run_pass(in, std::integral_constant<int, kDigits>{});
         }
         src_keys = dk;
         src_vals = dv;

@@ -756,6 +756,7 @@ __global__ __launch_bounds__(256, 4) void rescore_select_kernel(RescoreParams p)
     const int t = threadIdx.x % TPQ;
     const int64_t q = (int64_t)blockIdx.x * QPB + threadIdx.x / TPQ;
     const bool q_ok = q < p.n_q && (p.only_flagged == nullptr || p.only_flagged[q] != 0);
+    if (p.only_flagged != nullptr && __syncthreads_or(q_ok ? 1 : 0) == 0) return;   // no flagged query in this workgroup
     const int CAP = p.cap;
     const int n_cand = p.n_splits * 2 * p.KP;
     const int qtile = (int)(q / (32 * p.NB)), g = (int)((q / 32) % p.NB), jq = (int)(q % 32);

@@ -18,7 +18,9 @@ class _GatherSumRows(torch.autograd.Function):
         _need_cuda(weight, ids)
         w, idc = _f32c(weight), _i64c(ids)
         bag = idc.shape[-1]
-        n = idc.numel() // max(bag, 1)
+        n = 1
+        for extent in idc.shape[:-1]:     # bags, also when they are empty (bag == 0: every output row is zero)
+            n *= extent
         out = torch.empty(*idc.shape[:-1], w.shape[1], dtype=torch.float32, device=w.device)
         hmx.check(_L().hmx_gather_sum_rows_f32(hmx.ptr(w), w.shape[0], w.shape[1], hmx.ptr(idc), n, bag, hmx.ptr(out),
                                                _s()), "hmx_gather_sum_rows_f32")

@@ -127,6 +127,7 @@ PROTOTYPES = {
     "hmx_attn_fwd": (c_int, [P, P, P, I64, I64, I64, I64, I64, P, P, P]),
     "hmx_attn_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, P, P, P, P, P]),
     "hmx_profile_enable": (c_int, [c_int]),
+    "hmx_profile_filter": (c_int, [c_char_p]),
     "hmx_profile_collect": (c_int, [c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)]),
 }
 
@@ -169,7 +170,9 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def profile_enable(on=True):
+def profile_enable(on=True, only=None):
+    """Event brackets around the tagged kernels on / off; only = a tag: record that tag alone."""
+    check(lib().hmx_profile_filter(only.encode() if only else None), "hmx_profile_filter")
     check(lib().hmx_profile_enable(1 if on else 0), "hmx_profile_enable")
 
 

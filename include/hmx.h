@@ -453,6 +453,9 @@ int hmx_block_pre_bwd(const hmx_block_args* a, void* stream);
  * count, and forgets them.  Tags: "topk_coarse_bf16", "topk_coarse_f32", "gather_rows", "gather_rows_bf16", "scatter_segment_sum".
  * ------------------------------------------------------------------------------- */
 int hmx_profile_enable(int on);
+/* Restricts recording to spans with this tag (NULL or "": every tag again).  Every recorded span costs two event
+ * records on the stream; a timed region that wants one kernel's duration records that kernel alone. */
+int hmx_profile_filter(const char* tag);
 int hmx_profile_collect(const char* tag, double* total_ms, int64_t* launches);
 
 /* =================================================================================

@@ -88,10 +88,11 @@ def test_scatter_add_extreme_skew_bit_exact(n, distinct, d):
 
 
 @pytest.mark.parametrize("rows,n,d,dup", [(3_000_000, 600_000, 16, 0.5), (70_000, 300_000, 8, 0.0), (200, 270_000, 4, 0.0),
-                                          (4_000_001, 280_000, 64, 0.3), (65_536, 4097, 12, 0.0)])
+                                          (4_000_001, 280_000, 64, 0.3), (65_536, 4097, 12, 0.0),
+                                          (200_000, 300_000, 8, 0.4), (100_000, 5000, 16, 0.3), (262_143, 270_000, 4, 0.2)])
 def test_scatter_add_multi_pass_sort_bit_exact(rows, n, d, dup):
     """Enough entries for the sort's scanned tile prefixes (more than 64 tiles of 4096) and key widths of one, two
-    and three digits; `dup` of the entries repeat a few thousand ids, so equal keys sit in many tiles and any loss of
+    and three digits, including the 17- and 18-bit widths that are sorted as two 9-bit digits; `dup` of the entries repeat a few thousand ids, so equal keys sit in many tiles and any loss of
     their original order would change the fp32 sums."""
     g = torch.Generator().manual_seed(rows % 1000 + n)
     ids = torch.randint(0, rows, (n,), generator=g)
