@@ -246,11 +246,12 @@ extern "C" size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows
 
 static int scatter_add_impl(const float* grad_rows, const int64_t* ids, const int64_t* token_type, int64_t want_type,
                             int64_t n, int64_t d, float* grad_table, int64_t n_rows, int64_t padding_idx,
-                            void* workspace, size_t workspace_bytes, hipStream_t s) {
+                            void* workspace, size_t workspace_bytes, hipStream_t s, uint8_t* row_flags = nullptr) {
     const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(grad_rows) | reinterpret_cast<uintptr_t>(grad_table)) % 16 == 0);
     void* span = hmx_profile_begin("scatter_segment_sum", s);
     const int rc = hmx_seg::sorted_segment_add(hmx_seg::PlainRows{grad_rows}, vec, ids, token_type, want_type, n, d,
-                                               grad_table, n_rows, padding_idx, workspace, workspace_bytes, s);
+                                               grad_table, n_rows, padding_idx, workspace, workspace_bytes, s, nullptr,
+                                               nullptr, row_flags);
     hmx_profile_end(span, s);
     return rc;
 }
@@ -301,11 +302,12 @@ extern "C" int hmx_scatter_add_rows_f32_static(const float* grad_rows, const int
 
 extern "C" int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
                                         int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
-                                        int64_t padding_idx, void* workspace, size_t workspace_bytes, void* stream) {
+                                        int64_t padding_idx, uint8_t* row_flags, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
     HMX_ENTER();
     if (n < 0 || d <= 0 || n_rows <= 0 || n >= ((int64_t)1 << 31) || n_rows >= ((int64_t)1 << 31)) return HMX_EINVAL;
     if (n == 0) return HMX_OK;
     if (!grad_rows || !ids || !grad_table || !workspace) return HMX_EINVAL;
     return scatter_add_impl(grad_rows, ids, token_type, want_type, n, d, grad_table, n_rows, padding_idx, workspace,
-                            workspace_bytes, (hipStream_t)stream);
+                            workspace_bytes, (hipStream_t)stream, row_flags);
 }

@@ -681,8 +681,8 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
                         int64_t n_inb, int64_t hard_ld, int64_t inb_flags, float temperature, int normalize, float* logits,
                         const float* lse,
                         const float* q_inv, const float* k_inv, const float* grad_row_loss, const float* dq_unit,
-                        float* dq, float* dk, float* dtable, const int64_t* group_start, int64_t n_groups, int64_t period,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        float* dq, float* dk, float* dtable, uint8_t* dtable_flags, const int64_t* group_start,
+                        int64_t n_groups, int64_t period, void* workspace, size_t workspace_bytes, void* stream) {
     if (m == 0) return HMX_OK;
     const bool grouped = group_start != nullptr && n_hard > 0;
     if (grouped && (n_groups <= 0 || period <= 0 || period > kMaxPeriod || period > n_hard)) return HMX_EINVAL;
@@ -746,11 +746,12 @@ static int nce_bwd_impl(const float* q, const float* k, int64_t m, int64_t d, co
             HMX_CHECK_LAUNCH();
             PlainRows src{rows};
             rc = sorted_segment_add(src, true, IdSource(ids), nullptr, 0, n, d, dtable, n_rows, -1,
-                                    static_cast<char*>(workspace) + used, workspace_bytes - used, s, &skeys, &sentinel);
+                                    static_cast<char*>(workspace) + used, workspace_bytes - used, s, &skeys, &sentinel,
+                                    dtable_flags);
         } else {
             WeightedRows src{q, logits, (int)n_hard, C, 1};
             rc = sorted_segment_add(src, true, IdSource(hard_ids), nullptr, 0, n, d, dtable, n_rows, -1, workspace, workspace_bytes,
-                                    s, &skeys, &sentinel);
+                                    s, &skeys, &sentinel, dtable_flags);
         }
         if (rc != HMX_OK) return rc;
         if (normalize) {
@@ -769,13 +770,13 @@ extern "C" int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_
                                int64_t n_inb, int64_t hard_ld, int64_t inb_flags, float temperature, int normalize,
                                float* logits, const float* lse,
                                const float* q_inv, const float* k_inv, const float* grad_row_loss,
-                               const float* dq_unit, float* dq, float* dk, float* dtable, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               const float* dq_unit, float* dq, float* dk, float* dtable, uint8_t* dtable_flags,
+                               void* workspace, size_t workspace_bytes, void* stream) {
     HMX_ENTER();
     if (hard_ld > 0 && hard_ld != n_hard) return HMX_EINVAL;     // every hard slot is read here
     return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, hard_ld, inb_flags, temperature,
-                        normalize, logits, lse, q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, nullptr, 0, 0, workspace,
-                        workspace_bytes, stream);
+                        normalize, logits, lse, q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, dtable_flags, nullptr, 0, 0,
+                        workspace, workspace_bytes, stream);
 }
 
 extern "C" int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m, int64_t d, const float* table,
@@ -783,12 +784,12 @@ extern "C" int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m
                                        int64_t n_inb, int64_t hard_ld, int64_t inb_flags, float temperature, int normalize,
                                        float* logits, const float* lse,
                                        const float* q_inv, const float* k_inv, const float* grad_row_loss,
-                                       const float* dq_unit, float* dq, float* dk, float* dtable,
+                                       const float* dq_unit, float* dq, float* dk, float* dtable, uint8_t* dtable_flags,
                                        const int64_t* group_start, int64_t n_groups, int64_t period, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     HMX_ENTER();
     if (n_hard > 0 && !group_start) return HMX_EINVAL;
     return nce_bwd_impl(q, k, m, d, table, n_rows, hard_ids, n_hard, inb_idx, n_inb, hard_ld, inb_flags, temperature,
-                        normalize, logits, lse, q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, group_start, n_groups,
-                        period, workspace, workspace_bytes, stream);
+                        normalize, logits, lse, q_inv, k_inv, grad_row_loss, dq_unit, dq, dk, dtable, dtable_flags, group_start,
+                        n_groups, period, workspace, workspace_bytes, stream);
 }

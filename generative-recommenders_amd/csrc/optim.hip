@@ -179,6 +179,142 @@ __global__ __launch_bounds__(kThreads) void adamw_kernel(const hmx_adamw_tensor*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Embedding tables: the same update, organised by ROWS.  A step's dense table gradient is zero outside the few
+// hundred thousand rows the batch touched; with per-row flags (set by the scatter-add kernels) the gradient of an
+// untouched row is not read (it is zero), a touched row's gradient is zeroed and its flag cleared once it has been
+// used -- so the buffer is already the next step's zero-filled gradient -- and the bf16 scoring copy of the table
+// (rows + largest row norm) is written from the registers that hold the updated parameters.
+constexpr int kTableRows = 256;        // rows per workgroup
+constexpr int kMaxTables = 8;
+struct TableList {
+    hmx_adamw_table t[kMaxTables];
+    int block0[kMaxTables + 1];        // first workgroup of each table
+    int n;
+};
+
+__device__ __forceinline__ int table_of(const TableList& tl, int b) {
+    int i = 0;
+    while (i + 1 < tl.n && tl.block0[i + 1] <= b) ++i;
+    return i;
+}
+
+// partial[blockIdx.x] = sum of squares of the gradient rows of this workgroup's row block (flagged rows only)
+__global__ __launch_bounds__(kThreads) void table_sumsq_kernel(TableList tl, float* __restrict__ partial) {
+    __shared__ float wave_part[kThreads / 64];
+    const int ti = table_of(tl, blockIdx.x);
+    const hmx_adamw_table t = tl.t[ti];
+    const int cpr = (int)(t.d / 4);
+    int lpr = 1;
+    while (lpr < cpr) lpr <<= 1;
+    const int lane_c = threadIdx.x & (lpr - 1), rows_per_pass = kThreads / lpr;
+    const int64_t r0 = (int64_t)(blockIdx.x - tl.block0[ti]) * kTableRows;
+    float s = 0.f;
+    for (int rr = threadIdx.x / lpr; rr < kTableRows; rr += rows_per_pass) {
+        const int64_t r = r0 + rr;
+        if (r >= t.n_rows || lane_c >= cpr) continue;
+        if (t.row_flags != nullptr && t.row_flags[r] == 0) continue;
+        const float4 v = ldnt(t.g + r * t.d, lane_c);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = block_sum(s, wave_part);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(kThreads) void adamw_table_kernel(TableList tl, AdamHyper h, const float* __restrict__ grad_scale) {
+    __shared__ float wave_max[kThreads / 64];
+    const int ti = table_of(tl, blockIdx.x);
+    const hmx_adamw_table t = tl.t[ti];
+    const int cpr = (int)(t.d / 4);
+    int lpr = 1;
+    while (lpr < cpr) lpr <<= 1;
+    const int lane_c = threadIdx.x & (lpr - 1), rows_per_pass = kThreads / lpr;
+    const int64_t r0 = (int64_t)(blockIdx.x - tl.block0[ti]) * kTableRows;
+    const float gs = grad_scale ? *grad_scale : 1.0f;
+    float best = 0.f;
+    // two rows per thread in flight
+    for (int rr = threadIdx.x / lpr; rr < kTableRows; rr += 2 * rows_per_pass) {
+        int64_t r[2] = {r0 + rr, r0 + rr + rows_per_pass};
+        bool live[2], touched[2];
+        float4 p4[2], g4[2], m4[2], v4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            live[u] = r[u] < t.n_rows && rr + u * rows_per_pass < kTableRows && lane_c < cpr;
+            touched[u] = live[u] && (t.row_flags == nullptr || t.row_flags[r[u]] != 0);
+            g4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live[u]) {
+                p4[u] = ldnt(t.p + r[u] * t.d, lane_c);
+                m4[u] = ldnt(t.m + r[u] * t.d, lane_c);
+                v4[u] = ldnt(t.v + r[u] * t.d, lane_c);
+                if (touched[u]) g4[u] = ldnt(t.g + r[u] * t.d, lane_c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float n2 = 0.f;
+            if (live[u]) {
+                g4[u].x *= gs; g4[u].y *= gs; g4[u].z *= gs; g4[u].w *= gs;
+                adamw1(p4[u].x, g4[u].x, m4[u].x, v4[u].x, h);
+                adamw1(p4[u].y, g4[u].y, m4[u].y, v4[u].y, h);
+                adamw1(p4[u].z, g4[u].z, m4[u].z, v4[u].z, h);
+                adamw1(p4[u].w, g4[u].w, m4[u].w, v4[u].w, h);
+                stnt(t.p + r[u] * t.d, lane_c, p4[u]);
+                stnt(t.m + r[u] * t.d, lane_c, m4[u]);
+                stnt(t.v + r[u] * t.d, lane_c, v4[u]);
+                if (touched[u] && t.row_flags != nullptr) {      // used: back to the zero gradient, flag cleared
+                    stnt(t.g + r[u] * t.d, lane_c, make_float4(0.f, 0.f, 0.f, 0.f));
+                    if (lane_c == 0) t.row_flags[r[u]] = 0;
+                }
+                if (t.bf16_out != nullptr) {
+                    uint2 o;
+                    o.x = hmx_pack_bf16x2(p4[u].x, p4[u].y);
+                    o.y = hmx_pack_bf16x2(p4[u].z, p4[u].w);
+                    *reinterpret_cast<uint2*>(t.bf16_out + r[u] * t.bf16_ld + 4 * lane_c) = o;
+                    n2 = p4[u].x * p4[u].x + p4[u].y * p4[u].y + p4[u].z * p4[u].z + p4[u].w * p4[u].w;
+                }
+            }
+            if (t.bf16_out != nullptr) {     // row norm: over the lpr lanes of the row (wave-uniform branch)
+                for (int off = lpr >> 1; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
+                best = fmaxf(best, n2);
+            }
+        }
+    }
+    if (t.bf16_out != nullptr && t.bf16_max_norm != nullptr) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = wave_max[0];
+#pragma unroll
+            for (int i = 1; i < kThreads / 64; ++i) m = fmaxf(m, wave_max[i]);
+            // slightly inflated so that the rounding of this reduction can never under-state a norm
+            atomicMax(reinterpret_cast<unsigned*>(t.bf16_max_norm), __float_as_uint(sqrtf(m) * 1.0001f));
+        }
+    }
+}
+
+// host side: the by-value table list of a launch, or false when a table has an unsupported shape
+bool make_table_list(const hmx_adamw_table* tables, int64_t n_tables, TableList& tl) {
+    if (n_tables < 0 || n_tables > kMaxTables || (n_tables > 0 && !tables)) return false;
+    tl.n = (int)n_tables;
+    int b = 0;
+    for (int i = 0; i < tl.n; ++i) {
+        const hmx_adamw_table& t = tables[i];
+        if (!t.p || !t.g || !t.m || !t.v || t.n_rows <= 0 || t.d <= 0 || t.d % 4 != 0 || t.d > 256) return false;
+        if (((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.m) |
+              reinterpret_cast<uintptr_t>(t.v)) & 15) != 0)
+            return false;
+        if (t.bf16_out != nullptr && (t.bf16_ld < t.d || t.bf16_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(t.bf16_out) & 7) != 0))
+            return false;
+        tl.t[i] = t;
+        tl.block0[i] = b;
+        b += (int)hmx_ceil_div(t.n_rows, kTableRows);
+    }
+    tl.block0[tl.n] = b;
+    return true;
+}
+
 bool list_ok(const void* tensors, const void* chunk_start, int64_t n_tensors, int64_t total_chunks) {
     return tensors && chunk_start && n_tensors > 0 && n_tensors <= kMaxTensors && total_chunks > 0 &&
            total_chunks < ((int64_t)1 << 31);
@@ -192,18 +328,49 @@ extern "C" size_t hmx_grad_norm_workspace_bytes(int64_t total_chunks) {
     return hmx_align_up((size_t)(total_chunks > 0 ? total_chunks : 1) * sizeof(float), 256);
 }
 
+extern "C" int64_t hmx_adamw_table_blocks(int64_t n_rows) { return n_rows > 0 ? hmx_ceil_div(n_rows, kTableRows) : 0; }
+
 extern "C" int hmx_grad_norm_f32(const hmx_adamw_tensor* tensors, const int32_t* chunk_start, int64_t n_tensors,
-                                 int64_t total_chunks, float max_norm, void* workspace, size_t workspace_bytes,
-                                 float* norm_out, void* stream) {
+                                 int64_t total_chunks, const hmx_adamw_table* tables, int64_t n_tables, float max_norm,
+                                 void* workspace, size_t workspace_bytes, float* norm_out, void* stream) {
     HMX_ENTER();
-    if (!list_ok(tensors, chunk_start, n_tensors, total_chunks) || !workspace || !norm_out) return HMX_EINVAL;
-    if (workspace_bytes < hmx_grad_norm_workspace_bytes(total_chunks)) return HMX_EWORKSPACE;
+    TableList tl{};
+    if (!make_table_list(tables, n_tables, tl) || !workspace || !norm_out) return HMX_EINVAL;
+    if (n_tensors == 0) total_chunks = 0;
+    if (n_tensors != 0 && !list_ok(tensors, chunk_start, n_tensors, total_chunks)) return HMX_EINVAL;
+    const int64_t n_part = total_chunks + tl.block0[tl.n];
+    if (n_part <= 0) return HMX_EINVAL;
+    if (workspace_bytes < hmx_grad_norm_workspace_bytes(n_part)) return HMX_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partial = static_cast<float*>(workspace);
     void* span = hmx_profile_begin("optimizer", s);
-    hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)total_chunks), dim3(kThreads), 0, s, tensors, chunk_start,
-                       (int)n_tensors, partial);
-    hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(1024), 0, s, partial, (int)total_chunks, max_norm, norm_out);
+    if (total_chunks > 0)
+        hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)total_chunks), dim3(kThreads), 0, s, tensors, chunk_start,
+                           (int)n_tensors, partial);
+    if (tl.block0[tl.n] > 0)
+        hipLaunchKernelGGL(table_sumsq_kernel, dim3((unsigned)tl.block0[tl.n]), dim3(kThreads), 0, s, tl, partial + total_chunks);
+    hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(1024), 0, s, partial, (int)n_part, max_norm, norm_out);
+    hmx_profile_end(span, s);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_adamw_tables_step_f32(const hmx_adamw_table* tables, int64_t n_tables, float lr, float beta1, float beta2,
+                                         float eps, float weight_decay, int64_t step, const float* grad_scale, void* stream) {
+    HMX_ENTER();
+    TableList tl{};
+    if (!make_table_list(tables, n_tables, tl) || n_tables < 1 || step < 1) return HMX_EINVAL;
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && lr >= 0.f)) return HMX_EINVAL;
+    AdamHyper h{lr, beta1, beta2, eps, weight_decay, 0.f, 0.f};
+    h.bias_correction1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+    h.bias_correction2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < tl.n; ++i)
+        if (tl.t[i].bf16_out != nullptr && tl.t[i].bf16_max_norm != nullptr &&
+            hipMemsetAsync(tl.t[i].bf16_max_norm, 0, sizeof(float), s) != hipSuccess)
+            return HMX_ELAUNCH;
+    void* span = hmx_profile_begin("optimizer", s);
+    hipLaunchKernelGGL(adamw_table_kernel, dim3((unsigned)tl.block0[tl.n]), dim3(kThreads), 0, s, tl, h, grad_scale);
     hmx_profile_end(span, s);
     HMX_CHECK_LAUNCH();
     return HMX_OK;

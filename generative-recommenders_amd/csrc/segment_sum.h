@@ -139,6 +139,7 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
                                                                     int64_t n, int cpr, int lpr_log2, int S,
                                                                     int stage_bytes, uint32_t sentinel,
                                                                     float* __restrict__ grad_table,
+                                                                    uint8_t* __restrict__ row_flags,
                                                                     float* __restrict__ head_piece,
                                                                     float* __restrict__ tail_piece) {
     using V = typename VecT<VEC>::type;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
                     } else if (whole[u]) {
                         vadd(cur[u], acc);
                         (reinterpret_cast<V*>(grad_table) + (int64_t)key[u] * cpr)[c] = cur[u];
+                        if (row_flags != nullptr && c == 0) row_flags[key[u]] = 1;
                     } else if (!starts_true[u]) {
                         reinterpret_cast<V*>(head_piece)[sb * cpr + c] = acc;
                     } else {
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(kBlock) void segment_sum_balanced_kernel(Src src, c
                                                                       const typename Src::Val* __restrict__ svals,
                                                                       int64_t n, int cpr, int lpr_log2,
                                                                       uint32_t sentinel, float* __restrict__ grad_table,
+                                                                      uint8_t* __restrict__ row_flags,
                                                                       float* __restrict__ head_piece,
                                                                       float* __restrict__ tail_piece) {
     using V = typename VecT<VEC>::type;
@@ -362,6 +365,7 @@ __global__ __launch_bounds__(kBlock) void segment_sum_balanced_kernel(Src src, c
                     V t = *dst;
                     vadd(t, acc);
                     *dst = t;
+                    if (row_flags != nullptr && c == 0) row_flags[cur] = 1;
                 } else if (!starts_true) {
                     reinterpret_cast<V*>(head_piece)[b * cpr + c] = acc;
                 } else {
@@ -427,6 +431,7 @@ template <int VEC, int SB>
 __global__ __launch_bounds__(kBlock) void segment_join_kernel(const uint32_t* __restrict__ skeys, int64_t n, int cpr,
                                                               int lpr_log2, uint32_t sentinel,
                                                               float* __restrict__ grad_table,
+                                                              uint8_t* __restrict__ row_flags,
                                                               const float* __restrict__ head_piece,
                                                               const float* __restrict__ tail_piece) {
     using V = typename VecT<VEC>::type;
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(kBlock) void segment_join_kernel(const uint32_t* __
                 V cur = *dst;
                 vadd(cur, acc);
                 *dst = cur;
+                if (row_flags != nullptr && c == 0) row_flags[key] = 1;
             }
         }
         if constexpr (VEC == 4) {
@@ -539,6 +545,7 @@ __global__ __launch_bounds__(kBlock) void segment_join_kernel(const uint32_t* __
                     V cur = *dst;
                     vadd(cur, acc);
                     *dst = cur;
+                    if (row_flags != nullptr && lane_c == 0) row_flags[rkey] = 1;
                 }
             }
         }
@@ -569,11 +576,13 @@ inline size_t workspace_bytes(int64_t n, int64_t n_rows, int64_t d) {
 // table[ids[e]] += value(e) for e in [0, n).  `vec`: rows and table are 16-byte aligned and d % 4 == 0.
 // sorted_keys_out (optional) receives the device pointer of the sorted keys inside the workspace (n entries,
 // `sentinel_out` marks entries that did not contribute; they sort last).
+// row_flags (optional, n_rows bytes): row_flags[r] = 1 is stored for every table row that receives a sum, so that a
+// consumer of a mostly-zero dense gradient (the optimizer, the data-parallel exchange) knows which rows to read.
 template <class Src>
 int sorted_segment_add(const Src& src, bool vec, const IdSource& ids, const int64_t* token_type, int64_t want_type,
                        int64_t n, int64_t d, float* table, int64_t n_rows, int64_t padding_idx, void* workspace,
                        size_t ws_bytes, hipStream_t s, const uint32_t** sorted_keys_out = nullptr,
-                       uint32_t* sentinel_out = nullptr) {
+                       uint32_t* sentinel_out = nullptr, uint8_t* row_flags = nullptr) {
     if (d > kMaxRowFloats) return HMX_EINVAL;
     const int bits = sort_bits(n_rows);
     using Val = typename Src::Val;
@@ -610,15 +619,15 @@ int sorted_segment_add(const Src& src, bool vec, const IdSource& ids, const int6
         constexpr int VEC = decltype(vec_tag)::value;
         if constexpr (Src::kBalanced) {
             hipLaunchKernelGGL((segment_sum_balanced_kernel<VEC, Src, SB>), dim3(grid3), dim3(kBlock), 0, s, src, skeys, svals,
-                               n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+                               n, (int)cpr, l2, sentinel, table, row_flags, head_piece, tail_piece);
         } else {
             hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&segment_sum_staged_kernel<VEC, Src>), kMaxStagedLds);
             hipLaunchKernelGGL((segment_sum_staged_kernel<VEC, Src>), dim3((unsigned)n_sb), dim3(kBlock), lds, s, src, skeys,
-                               svals, n, (int)cpr, l2, S, stage_bytes, sentinel, table, head_piece, tail_piece);
+                               svals, n, (int)cpr, l2, S, stage_bytes, sentinel, table, row_flags, head_piece, tail_piece);
         }
         hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&segment_join_kernel<VEC, SB>), (kBlock / 64) * kJoinLdsPerWave);
         hipLaunchKernelGGL((segment_join_kernel<VEC, SB>), dim3(grid4), dim3(kBlock), (kBlock / 64) * kJoinLdsPerWave, s, skeys,
-                           n, (int)cpr, l2, sentinel, table, head_piece, tail_piece);
+                           n, (int)cpr, l2, sentinel, table, row_flags, head_piece, tail_piece);
     };
     if (vec) run(std::integral_constant<int, 4>{});
     else run(std::integral_constant<int, 1>{});

@@ -20,6 +20,12 @@ class WgradDesc(ctypes.Structure):
                 ("dbias", c_void_p), ("accumulate", c_int32)]
 
 
+class AdamwTable(ctypes.Structure):
+    """hmx_adamw_table of include/hmx.h."""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n_rows", c_int64), ("d", c_int64),
+                ("row_flags", c_void_p), ("bf16_out", c_void_p), ("bf16_ld", c_int64), ("bf16_max_norm", c_void_p)]
+
+
 class BlockWeights(ctypes.Structure):
     """hmx_block_weights of include/hmx.h."""
     _fields_ = ([(n, c_void_p) for n in ("W1", "W2", "Wg", "Wu", "Wd")] + [("Win", c_void_p * 8), ("Wout", c_void_p * 8)] +
@@ -49,7 +55,7 @@ PROTOTYPES = {
     "hmx_gather_routed_f32": (c_int, [P, I64, P, I64, I64, P, P, I64, P, P]),
     "hmx_gather_gelu_rows_f32": (c_int, [P, I64, I64, P, I64, P, P]),
     "hmx_scatter_add_rows_workspace_bytes": (c_size_t, [I64, I64, I64]),
-    "hmx_scatter_add_rows_f32": (c_int, [P, P, P, I64, I64, I64, P, I64, I64, P, c_size_t, P]),
+    "hmx_scatter_add_rows_f32": (c_int, [P, P, P, I64, I64, I64, P, I64, I64, P, P, c_size_t, P]),
     "hmx_scatter_add_rows_static_scratch_bytes": (c_size_t, []),
     "hmx_scatter_add_rows_f32_static": (c_int, [P, P, P, I64, I64, I64, P, I64, I64, P]),
     "hmx_table_prepare_bf16": (c_int, [P, I64, I64, P, P, P]),
@@ -68,16 +74,18 @@ PROTOTYPES = {
     "hmx_pscan_bwd": (c_int, [P, P, P, I64, I64, I64, P, P, P]),
     "hmx_nce_fwd_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P, P, P]),
     "hmx_nce_bwd_workspace_bytes": (c_size_t, [I64, I64, I64, I64, I64]),
-    "hmx_nce_bwd_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P, P, P, P, P, P,
+    "hmx_nce_bwd_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P, P, P, P, P, P, P,
                                 c_size_t, P]),
     "hmx_nce_fwd_periodic_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P,
                                          P, P]),
     "hmx_nce_bwd_grouped_workspace_bytes": (c_size_t, [I64, I64, I64, I64, I64, I64, I64]),
     "hmx_nce_bwd_grouped_f32": (c_int, [P, P, I64, I64, P, I64, P, I64, P, I64, I64, I64, F, c_int, P, P, P, P, P, P, P, P,
-                                        P, P, I64, I64, P, c_size_t, P]),
+                                        P, P, P, I64, I64, P, c_size_t, P]),
     "hmx_adamw_chunk_elems": (I64, []),
     "hmx_grad_norm_workspace_bytes": (c_size_t, [I64]),
-    "hmx_grad_norm_f32": (c_int, [P, P, I64, I64, F, P, c_size_t, P, P]),
+    "hmx_adamw_table_blocks": (I64, [I64]),
+    "hmx_grad_norm_f32": (c_int, [P, P, I64, I64, ctypes.POINTER(AdamwTable), I64, F, P, c_size_t, P, P]),
+    "hmx_adamw_tables_step_f32": (c_int, [ctypes.POINTER(AdamwTable), I64, F, F, F, F, F, I64, P, P]),
     "hmx_adamw_step_f32": (c_int, [P, P, I64, I64, F, F, F, F, F, I64, P, c_int, P]),
     "hmx_rmsnorm_fwd": (c_int, [P, P, I64, I64, F, P, P, P]),
     "hmx_rmsnorm_bwd_blocks": (I64, [I64]),

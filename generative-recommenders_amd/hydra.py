@@ -615,7 +615,9 @@ class Hydra(nn.Module):
         w = self.shared_embeddings.item_emb.weight.detach()
         if self._prepared is None or self._prepared.table.data_ptr() != w.data_ptr():
             self._prepared = ops.PreparedTable(w)
-        elif refresh:
+        elif refresh and self._prepared.synced_version != w._version:
+            # (an optimizer step of optim.HmxAdamW rewrites the copy from the rows it has just updated and records
+            # the table's version; anything else that changed the table since then bumped the version)
             self._prepared.refresh()
         return self._prepared
 

@@ -51,14 +51,65 @@ def set_fused_table_grad(flag=True):
     _FUSE_TABLE_GRAD = bool(flag)
 
 
+class TableGrad:
+    """Book-keeping of a table's dense gradient in fused-table-gradient mode.  The buffer outlives the step: one byte
+    per row (`flags`) records which rows the step's scatter-adds wrote, the optimizer (optim.HmxAdamW) reads only
+    those rows, sets them back to zero and clears their flags, and declares the buffer `clean` -- it is then handed out
+    again as the next step's zero-filled gradient without a fill.  Anything else that writes the buffer must go
+    through scatter_add_rows / the fused loss (they set the flags) or call mark_dense()."""
+
+    def __init__(self, param):
+        self.buf = torch.zeros_like(param, memory_format=torch.contiguous_format)
+        self.flags = torch.zeros(param.shape[0], dtype=torch.uint8, device=param.device)
+        self.clean = False          # True: buf is all zero and flags are all clear (set by the optimizer)
+        self.dense = False          # True: rows were written without flags; consumers must read every row
+
+    def matches(self, param):
+        return self.buf.shape == param.shape and self.buf.device == param.device
+
+    def mark_dense(self):
+        self.dense = True
+
+
+_TABLE_GRADS = {}        # id(param) -> (weakref to the parameter, TableGrad)
+_FLAGS_BY_PTR = {}       # data_ptr of a tracked buffer -> TableGrad
+
+
+def table_grad_state(param):
+    """The TableGrad whose buffer is param.grad right now, or None."""
+    ent = _TABLE_GRADS.get(id(param))
+    if ent is None or ent[0]() is not param or param.grad is None or param.grad.data_ptr() != ent[1].buf.data_ptr():
+        return None
+    return ent[1]
+
+
 def _into_param_grad(param):
     """The tensor a fused table gradient should be added into, or None when the standard path applies."""
     if not (_FUSE_TABLE_GRAD and isinstance(param, torch.nn.Parameter) and param.is_leaf and param.requires_grad):
         return None
     if param.grad is None:
-        param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+        import weakref
+        ent = _TABLE_GRADS.get(id(param))
+        st = ent[1] if (ent is not None and ent[0]() is param and ent[1].matches(param)) else None
+        if st is None:
+            for k in [k for k, (ref, _) in _TABLE_GRADS.items() if ref() is None]:      # entries of parameters that are gone
+                _FLAGS_BY_PTR.pop(_TABLE_GRADS.pop(k)[1].buf.data_ptr(), None)
+            st = TableGrad(param)
+            _TABLE_GRADS[id(param)] = (weakref.ref(param), st)
+            _FLAGS_BY_PTR[st.buf.data_ptr()] = st
+        elif not st.clean:         # the last step's gradient was not consumed by an optimizer that cleans up
+            st.buf.zero_()
+            st.flags.zero_()
+        st.clean, st.dense = False, False
+        param.grad = st.buf
     g = param.grad
     return g if (g.is_contiguous() and g.dtype == torch.float32) else None
+
+
+def _row_flags_of(out):
+    """The row flags that go with a tracked table-gradient buffer (None for any other tensor)."""
+    st = _FLAGS_BY_PTR.get(out.data_ptr()) if out is not None else None
+    return st.flags if (st is not None and st.buf.shape == out.shape) else None
 
 
 def workspace(nbytes, device):
@@ -66,7 +117,8 @@ def workspace(nbytes, device):
 
 
 def scatter_add_rows(grad_rows, ids, n_rows, padding_idx=-1, token_type=None, want_type=0, out=None):
-    """Dense (n_rows, d) gradient: out[ids[i]] += grad_rows[i] (deterministic)."""
+    """Dense (n_rows, d) gradient: out[ids[i]] += grad_rows[i] (deterministic).  When `out` is a table gradient kept
+    by TableGrad, the rows written are flagged."""
     _need_cuda(grad_rows, ids, token_type)
     d = grad_rows.shape[-1]
     g = _f32c(grad_rows).view(-1, d)
@@ -79,8 +131,8 @@ def scatter_add_rows(grad_rows, ids, n_rows, padding_idx=-1, token_type=None, wa
     L = hmx.lib()
     ws = workspace(L.hmx_scatter_add_rows_workspace_bytes(n, n_rows, d), g.device)
     hmx.check(L.hmx_scatter_add_rows_f32(hmx.ptr(g), hmx.ptr(ids), hmx.ptr(tt), want_type, n, d, hmx.ptr(out), n_rows,
-                                         padding_idx, hmx.ptr(ws), ws.numel(), hmx.current_stream()),
-              "hmx_scatter_add_rows_f32")
+                                         padding_idx, hmx.ptr(_row_flags_of(out)), hmx.ptr(ws), ws.numel(),
+                                         hmx.current_stream()), "hmx_scatter_add_rows_f32")
     return out
 
 
@@ -262,15 +314,16 @@ class _FusedNCE(torch.autograd.Function):
             hmx.check(L.hmx_nce_bwd_grouped_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
                                                 hmx.ptr(iid), n_inb, hard_ld, flags, temperature, normalize, hmx.ptr(coef),
                                                 hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq_unit),
-                                                hmx.ptr(dq), hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(gs), ng, period,
-                                                hmx.ptr(ws), ws.numel(), hmx.current_stream()), "hmx_nce_bwd_grouped_f32")
+                                                hmx.ptr(dq), hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(_row_flags_of(dtable)),
+                                                hmx.ptr(gs), ng, period, hmx.ptr(ws), ws.numel(), hmx.current_stream()),
+                      "hmx_nce_bwd_grouped_f32")
         else:
             ws = workspace(L.hmx_nce_bwd_workspace_bytes(m, d, n_rows, n_hard, n_inb), dev)
             hmx.check(L.hmx_nce_bwd_f32(hmx.ptr(q), hmx.ptr(k), m, d, hmx.ptr(tab), n_rows, hmx.ptr(hid), n_hard,
                                         hmx.ptr(iid), n_inb, hard_ld, flags, temperature, normalize, hmx.ptr(coef),
                                         hmx.ptr(lse), hmx.ptr(q_inv), hmx.ptr(k_inv), hmx.ptr(g), hmx.ptr(dq_unit),
-                                        hmx.ptr(dq), hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(ws), ws.numel(),
-                                        hmx.current_stream()), "hmx_nce_bwd_f32")
+                                        hmx.ptr(dq), hmx.ptr(dk), hmx.ptr(dtable), hmx.ptr(_row_flags_of(dtable)),
+                                        hmx.ptr(ws), ws.numel(), hmx.current_stream()), "hmx_nce_bwd_f32")
         return (dq, dk, (dtable if (want_table and fused_dst is None) else None), None, None, None, None, None, None,
                 None)
 
@@ -297,6 +350,18 @@ def _dpad(d):
     return p
 
 
+_PREPARED_BY_PTR = {}     # data_ptr of a table -> weakref of its PreparedTable (the optimizer keeps the copy current)
+
+
+def prepared_copy_of(param):
+    """The live PreparedTable of this parameter's storage, if one exists (optim.HmxAdamW writes it during its step)."""
+    ref = _PREPARED_BY_PTR.get(param.data_ptr())
+    pt = ref() if ref is not None else None
+    if pt is None or pt.table.data_ptr() != param.data_ptr() or pt.table.shape != param.shape:
+        return None
+    return pt
+
+
 class PreparedTable:
     """bf16 copy (row stride = next power of two >= max(16, d)) and largest row norm of an fp32
     table shard, as the bf16 coarse scoring pass needs them.  Re-run refresh() after the table's
@@ -310,7 +375,9 @@ class PreparedTable:
             raise hmx.HmxError("bf16 coarse scoring supports d <= 128")
         self.bf16 = torch.empty(n, _dpad(d), dtype=torch.int16, device=table.device)
         self.max_row_norm = torch.zeros(1, dtype=torch.float32, device=table.device)
+        self.synced_version = None      # table._version at which an optimizer step last rewrote this copy itself
         self.refresh()
+        _PREPARED_BY_PTR[self.table.data_ptr()] = __import__("weakref").ref(self)
 
     def refresh(self, table=None):
         if table is not None:
@@ -375,6 +442,9 @@ def touched_rows(x):
     kernel, then a compaction of the per-row flags (host sync: the count)."""
     _need_cuda(x)
     x = _f32c(x)
+    st = _FLAGS_BY_PTR.get(x.data_ptr())
+    if st is not None and st.buf.shape == x.shape and not st.dense:
+        return st.flags.nonzero().flatten()        # a table gradient with row flags: the flagged rows, no pass over x
     flags = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
     hmx.check(hmx.lib().hmx_row_any_nonzero_f32(hmx.ptr(x), x.shape[0], x.shape[1], hmx.ptr(flags),
                                                 hmx.current_stream()), "hmx_row_any_nonzero_f32")

@@ -9,23 +9,34 @@ by `optimizer.step()` of `HmxAdamW(model.parameters(), ..., max_grad_norm=1.0)`:
 norm, one pass over parameters / gradients / moments for the update, the clip factor applied inside the update and
 never leaving the device.  It is a torch.optim.Optimizer (param_groups, state_dict with step / exp_avg / exp_avg_sq per
 parameter, LR schedulers), so the rest of the loop is unchanged.
+
+Embedding tables whose dense gradient is kept by ops.TableGrad (fused table gradients: ops.set_fused_table_grad) take
+a row-wise form of the same update: only the rows the step's scatter-adds flagged have their gradient read, those rows
+are set back to zero and un-flagged once used -- so the buffer is the next step's zero gradient and `zero_grad` costs
+nothing for it; after step() such a table's .grad therefore reads all zero -- and the table's bf16 scoring copy
+(ops.PreparedTable), if one exists, is rewritten from the updated rows in the same pass.  Values are those of the
+dense update, bit for bit.  `sparse_table_grads=False` switches this off.
 """
+import ctypes
+
 import numpy as np
 import torch
 
 from . import hmx
+from . import ops
 
 _DESC = np.dtype([("p", np.uint64), ("g", np.uint64), ("m", np.uint64), ("v", np.uint64), ("n", np.int64)])
 
 
 class HmxAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None,
-                 keep_clipped_grads=False):
+                 keep_clipped_grads=False, sparse_table_grads=True):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("HmxAdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
         self.keep_clipped_grads = bool(keep_clipped_grads)     # also write the clipped gradients back into .grad
+        self.sparse_table_grads = bool(sparse_table_grads)
         self.last_grad_norm = None                             # device tensor (norm, clip factor) of the last step
         self._tables = {}                                      # per group index: cached layout for the active set
 
@@ -90,6 +101,31 @@ class HmxAdamW(torch.optim.Optimizer):
             cached["desc"].copy_(staged, non_blocking=True)
         return cached
 
+    def _row_wise(self, p):
+        """The TableGrad of a parameter that takes the row-wise kernel, else None."""
+        if not self.sparse_table_grads or self.keep_clipped_grads or p.dim() != 2:
+            return None
+        tg = ops.table_grad_state(p)
+        if tg is None or tg.dense or p.shape[1] % 4 != 0 or p.shape[1] > 256 or not p.is_contiguous():
+            return None
+        return tg
+
+    def _table_array(self, pairs, with_copy):
+        """(ctypes array of hmx_adamw_table for these (parameter, TableGrad) pairs, the PreparedTable of each or None)."""
+        arr = (hmx.AdamwTable * max(len(pairs), 1))()
+        copies = []
+        for i, (p, tg) in enumerate(pairs):
+            st = self.state[p]
+            a = arr[i]
+            a.p, a.g, a.m, a.v = p.data_ptr(), tg.buf.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            a.n_rows, a.d = p.shape[0], p.shape[1]
+            a.row_flags = tg.flags.data_ptr()
+            pt = ops.prepared_copy_of(p) if with_copy else None
+            if pt is not None:
+                a.bf16_out, a.bf16_ld, a.bf16_max_norm = pt.bf16.data_ptr(), pt.bf16.shape[1], pt.max_row_norm.data_ptr()
+            copies.append(pt)
+        return arr, copies
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._tables = {}              # the loaded moments live elsewhere
@@ -102,33 +138,58 @@ class HmxAdamW(torch.optim.Optimizer):
                 loss = closure()
         L = hmx.lib()
         stream = hmx.current_stream()
-        tables = []
+        tables = []          # flat tensor lists: (group, parameters, device table, step)
+        row_tables = []      # embedding tables on the row-wise kernel: (group, parameters, their TableGrad, step)
+        n_row_wise = 0
         for gi, group in enumerate(self.param_groups):
             self._init_state(group)
             # one launch per (group, step count): parameters that skipped steps (no gradient) keep their own count
-            by_step = {}
+            by_step, rows_by_step = {}, {}
             for p in group["params"]:
-                if p.grad is not None:
-                    by_step.setdefault(int(self.state[p]["step"]), []).append(p)
+                if p.grad is None:
+                    continue
+                tg = self._row_wise(p) if n_row_wise < 8 else None       # one launch takes eight tables
+                n_row_wise += tg is not None
+                (rows_by_step if tg is not None else by_step).setdefault(int(self.state[p]["step"]), []).append(
+                    (p, tg) if tg is not None else p)
             for k, (st, active) in enumerate(sorted(by_step.items())):
                 tables.append((group, active, self._table((gi, k), active), st + 1))
-        if not tables:
+            for st, pairs in sorted(rows_by_step.items()):
+                row_tables.append((group, [p for p, _ in pairs], [t for _, t in pairs], st + 1))
+        if not tables and not row_tables:
             return loss
+        dev = (tables[0][1][0] if tables else row_tables[0][1][0]).device
         scale_ptr = None
         if self.max_grad_norm is not None:
             # clip_grad_norm_ takes one norm over every gradient handed to it: all groups together
             if len(tables) == 1:
                 allt = tables[0][2]
-            else:
+            elif tables:
                 allt = self._table(-1, [p for _, act, _, _ in tables for p in act])
-            dev = tables[0][1][0].device
-            ws = torch.empty(max(int(L.hmx_grad_norm_workspace_bytes(allt["chunks"])), 256), dtype=torch.uint8, device=dev)
+            else:
+                allt = None
+            all_rows = [(p, t) for _, ps, ts, _ in row_tables for p, t in zip(ps, ts)]
+            arr, _keep = self._table_array(all_rows, with_copy=False)
+            n_part = (allt["chunks"] if allt else 0) + sum(int(L.hmx_adamw_table_blocks(p.shape[0])) for p, _ in all_rows)
+            ws = torch.empty(max(int(L.hmx_grad_norm_workspace_bytes(n_part)), 256), dtype=torch.uint8, device=dev)
             norm = torch.empty(2, dtype=torch.float32, device=dev)
-            hmx.check(L.hmx_grad_norm_f32(allt["desc"].data_ptr(), allt["starts"].data_ptr(), len(allt["host"]),
-                                          allt["chunks"], float(self.max_grad_norm), ws.data_ptr(), ws.numel(),
-                                          norm.data_ptr(), stream), "hmx_grad_norm_f32")
+            hmx.check(L.hmx_grad_norm_f32(allt["desc"].data_ptr() if allt else None,
+                                          allt["starts"].data_ptr() if allt else None, len(allt["host"]) if allt else 0,
+                                          allt["chunks"] if allt else 0, arr, len(all_rows), float(self.max_grad_norm),
+                                          ws.data_ptr(), ws.numel(), norm.data_ptr(), stream), "hmx_grad_norm_f32")
             self.last_grad_norm = norm
             scale_ptr = norm.data_ptr() + 4
+        for group, ps, tgs, step in row_tables:
+            torch._foreach_add_([self.state[p]["step"] for p in ps], 1)
+            b1, b2 = group["betas"]
+            arr, copies = self._table_array(list(zip(ps, tgs)), with_copy=True)
+            hmx.check(L.hmx_adamw_tables_step_f32(arr, len(ps), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                  float(group["weight_decay"]), step, scale_ptr, stream),
+                      "hmx_adamw_tables_step_f32")
+            for p, tg, pt in zip(ps, tgs, copies):
+                tg.clean = True                    # gradient rows zeroed, flags cleared: the next step's zero gradient
+                if pt is not None:
+                    pt.synced_version = p._version
         for group, active, t, step in tables:
             torch._foreach_add_([self.state[p]["step"] for p in active], 1)
             b1, b2 = group["betas"]

@@ -121,6 +121,11 @@ class GradientSync:
                 p.grad = torch.zeros_like(p)
         for p in dense_big:
             works.append(_all_reduce_sum(p.grad, self.group, async_op=True))
+            if p.grad.is_cuda:       # every row may change: a row-flagged table gradient is dense from here on
+                from . import ops
+                st = ops.table_grad_state(p)
+                if st is not None:
+                    st.mark_dense()
         pending_sparse = [self._sparse_begin(p, scale) for p in sparse]
         flat = self._bucket()
         if flat is not None:

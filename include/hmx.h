@@ -81,11 +81,15 @@ int hmx_gather_gelu_rows_f32(const float* table, int64_t n_rows, int64_t d, cons
  * zero, the pieces of one id are added in order, and the total is added to the row once.  (For ids with
  * at most 512 occurrences not straddling a cut this is the plain sum in increasing i.)
  * grad_table is NOT cleared here (the caller zero-fills or accumulates).
+ * row_flags (optional, n_rows bytes, NULL = not wanted): row_flags[r] = 1 is stored for every row r that receives a
+ * sum (other entries are left alone).  A step touches a few hundred thousand of the 4 M rows of the dense gradient;
+ * with the flags its consumers -- hmx_adamw_tables_step_f32, the data-parallel exchange -- read only those rows.
  * ------------------------------------------------------------------------------- */
 size_t hmx_scatter_add_rows_workspace_bytes(int64_t n, int64_t n_rows, int64_t d);
 int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const int64_t* token_type,
                              int64_t want_type, int64_t n, int64_t d, float* grad_table, int64_t n_rows,
-                             int64_t padding_idx, void* workspace, size_t workspace_bytes, void* stream);
+                             int64_t padding_idx, uint8_t* row_flags, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* The same scatter-add for callers that cannot allocate device memory or hand over a workspace: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.
@@ -209,7 +213,8 @@ int hmx_topk_merge(const int64_t* cand_ids, const float* cand_scores, int64_t n_
  * walks the keys again (same values up to fp32 summation order).
  * Backward takes grad_row_loss (m) and produces dq (m, d), dk (m, d) (both overwritten) and, when n_hard > 0,
  * ADDS the hard-negative gradient rows into dtable (n_rows, d), which must be zero on entry (the normalisation
- * Jacobian is applied in place to the rows it touched).  `logits` is overwritten.  d % 4 == 0, d <= 256,
+ * Jacobian is applied in place to the rows it touched); dtable_flags (optional): see row_flags of
+ * hmx_scatter_add_rows_f32.  `logits` is overwritten.  d % 4 == 0, d <= 256,
  * 16-byte aligned q / k / table / dq / dk / dtable.  Deterministic (sorted-run sums, no float atomics).
  * Index arguments.  hard_ids is (m, hard_ld) with hard_ld = 0 meaning n_hard; a shorter row (hard_ld < n_hard) is
  * allowed where the slots beyond it repeat (the periodic / grouped calls, period <= hard_ld), so the tiled copy of
@@ -227,7 +232,7 @@ int hmx_nce_bwd_f32(const float* q, const float* k, int64_t m, int64_t d, const 
                     const int64_t* hard_ids, int64_t n_hard, const void* inb_idx, int64_t n_inb, int64_t hard_ld,
                     int64_t inb_flags, float temperature, int normalize, float* logits, const float* lse, const float* q_inv,
                     const float* k_inv, const float* grad_row_loss, const float* dq_unit, float* dq, float* dk,
-                    float* dtable, void* workspace, size_t workspace_bytes, void* stream);
+                    float* dtable, uint8_t* dtable_flags, void* workspace, size_t workspace_bytes, void* stream);
 /* Hard negatives that repeat, which is how hydra3.py:905-919 builds them (each user's K mined ids, tiled over the n_hard
  * slots of all of that user's positions).
  * hmx_nce_fwd_periodic_f32: the caller guarantees hard_ids[i, s] == hard_ids[i, s % period] for every row; only the
@@ -251,8 +256,8 @@ int hmx_nce_bwd_grouped_f32(const float* q, const float* k, int64_t m, int64_t d
                             int64_t inb_flags, float temperature, int normalize, float* logits, const float* lse,
                             const float* q_inv,
                             const float* k_inv, const float* grad_row_loss, const float* dq_unit, float* dq, float* dk,
-                            float* dtable, const int64_t* group_start, int64_t n_groups, int64_t period, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            float* dtable, uint8_t* dtable_flags, const int64_t* group_start, int64_t n_groups,
+                            int64_t period, void* workspace, size_t workspace_bytes, void* stream);
 
 /* =================================================================================
  * Sequence encoder (hydra3.py).  Activations are (T = B*L tokens, features) row-major fp32.
@@ -463,7 +468,7 @@ int hmx_profile_collect(const char* tag, double* total_ms, int64_t* launches);
  * list of fp32 tensors.  `tensors` and `chunk_start` are DEVICE arrays: n_tensors descriptors, and n_tensors + 1
  * ascending int32 offsets with chunk_start[i + 1] - chunk_start[i] = ceil(tensors[i].n / hmx_adamw_chunk_elems()),
  * total_chunks = chunk_start[n_tensors].  n_tensors <= 1023.
- * hmx_grad_norm_f32: norm_out[0] = sqrt(sum of squares of all g) (clip_grad_norm_'s total norm, 2-norm),
+ * hmx_grad_norm_f32: norm_out[0] = sqrt(sum of squares of all g, tensors and tables) (clip_grad_norm_'s total norm),
  *   norm_out[1] = min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0); both stay on the device.  Deterministic:
  *   per-chunk partial sums added in a fixed order.
  * hmx_adamw_step_f32: for every element, with g' = g * (*grad_scale) (grad_scale: device scalar or NULL = 1):
@@ -479,11 +484,36 @@ typedef struct {
     float* v;        /* exp_avg_sq */
     int64_t n;       /* elements */
 } hmx_adamw_tensor;
+/* An embedding table of the same update, walked by rows (`tables` arguments are HOST arrays of at most eight, read
+ * before the call returns).  d % 4 == 0, d <= 256, 16-byte aligned p / g / m / v.
+ * row_flags (n_rows bytes or NULL): as left by hmx_scatter_add_rows_f32 -- rows with flag 0 hold a zero gradient and
+ *   it is not read; a flagged row's gradient is set back to zero and its flag cleared once the update has used it,
+ *   so that after the step g is again the all-zero dense gradient the next backward pass adds into (the zero-fill
+ *   of main.py:684's zero_grad and the reads of a gigabyte of zeros are what this saves).  NULL: every row is read
+ *   and g is left as it is.
+ * bf16_out (n_rows, bf16_ld) or NULL: receives the updated rows rounded to bf16 (the scoring copy that
+ *   hmx_table_prepare_bf16 would make; columns d .. bf16_ld of a row are not written) and bf16_max_norm the largest
+ *   updated row 2-norm. */
+typedef struct hmx_adamw_table {
+    float* p;
+    float* g;
+    float* m;
+    float* v;
+    int64_t n_rows, d;
+    uint8_t* row_flags;
+    uint16_t* bf16_out;
+    int64_t bf16_ld;
+    float* bf16_max_norm;
+} hmx_adamw_table;
 int64_t hmx_adamw_chunk_elems(void);
-size_t hmx_grad_norm_workspace_bytes(int64_t total_chunks);
+int64_t hmx_adamw_table_blocks(int64_t n_rows);
+/* workspace for hmx_grad_norm_f32: n_partials = total_chunks + the sum of hmx_adamw_table_blocks(n_rows) of the tables */
+size_t hmx_grad_norm_workspace_bytes(int64_t n_partials);
 int hmx_grad_norm_f32(const hmx_adamw_tensor* tensors, const int32_t* chunk_start, int64_t n_tensors,
-                      int64_t total_chunks, float max_norm, void* workspace, size_t workspace_bytes, float* norm_out,
-                      void* stream);
+                      int64_t total_chunks, const hmx_adamw_table* tables, int64_t n_tables, float max_norm,
+                      void* workspace, size_t workspace_bytes, float* norm_out, void* stream);
+int hmx_adamw_tables_step_f32(const hmx_adamw_table* tables, int64_t n_tables, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int64_t step, const float* grad_scale, void* stream);
 int hmx_adamw_step_f32(const hmx_adamw_tensor* tensors, const int32_t* chunk_start, int64_t n_tensors,
                        int64_t total_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
                        int64_t step, const float* grad_scale, int write_scaled_grads, void* stream);

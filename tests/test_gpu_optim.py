@@ -90,3 +90,67 @@ def test_two_groups_share_one_norm():
         opt.step()
     for p, q in zip(a, b):
         torch.testing.assert_close(q, p, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("d", [64, 60])
+def test_row_wise_table_update_with_flags_and_scoring_copy(d):
+    """Embedding tables in fused-table-gradient mode: the scatter-adds flag the rows they write, the optimizer reads
+    only those rows' gradients, zeroes them, clears the flags and rewrites the table's bf16 scoring copy.  Against the
+    dense form of the same optimizer (sparse_table_grads=False) on the same gathers: parameters and moments
+    bit-identical after three steps; the gradient buffer is zero after a step and is handed out again for the next
+    one; the scoring copy equals a fresh conversion of the updated table."""
+    from generative_recommenders_amd import ops
+    rows, n = 5003, 700
+    g = torch.Generator().manual_seed(d)
+    w0 = torch.randn(rows, d, generator=g) * 0.1
+    small0 = torch.randn(17, 9, generator=g)
+
+    def run(sparse):
+        w = torch.nn.Parameter(w0.clone().to(DEV))
+        small = torch.nn.Parameter(small0.clone().to(DEV))
+        opt = HmxAdamW([w, small], lr=1e-2, betas=(0.9, 0.98), weight_decay=0.1, max_grad_norm=1.0,
+                       sparse_table_grads=sparse)
+        prep = ops.PreparedTable(w.detach())
+        bufs, norms = [], []
+        for step in range(3):
+            gg = torch.Generator().manual_seed(100 + step)
+            ids = torch.randint(0, rows, (n,), generator=gg).to(DEV)
+            ids2 = torch.randint(0, rows, (n // 2,), generator=gg).to(DEV)
+            coef = torch.randn(n, d, generator=gg).to(DEV)
+            opt.zero_grad(set_to_none=True)
+            loss = (ops.gather_rows(w, ids, 0) * coef).sum() + ops.gather_rows(w, ids2, 0).square().sum() + small.sum()
+            loss.backward()
+            if sparse:
+                st = ops.table_grad_state(w)
+                touched = w.grad.abs().sum(1) > 0
+                assert st is not None and bool((st.flags[touched] == 1).all())      # every written row is flagged
+                assert int(st.flags.sum()) <= n + n // 2
+                bufs.append(w.grad.data_ptr())
+            opt.step()
+            norms.append(opt.last_grad_norm.clone())
+            if sparse:
+                assert float(w.grad.abs().sum()) == 0.0 and int(st.flags.sum()) == 0 and st.clean
+                assert prep.synced_version == w._version
+                fresh = ops.PreparedTable(w.detach().clone())
+                assert torch.equal(prep.bf16[:, :d], fresh.bf16[:, :d])
+                assert abs(float(prep.max_row_norm) - float(fresh.max_row_norm)) <= 1e-5 * float(fresh.max_row_norm)
+        return w, small, opt, bufs, norms
+
+    ops.set_fused_table_grad(True)
+    try:
+        wa, sa, oa, bufs, na = run(True)
+        wb, sb, ob, _, nb = run(False)
+    finally:
+        ops.set_fused_table_grad(False)
+    assert len(set(bufs)) == 1                       # one gradient buffer, never re-filled
+    for x, y in zip(na, nb):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=0)
+    if d == 64:      # 256 rows of 64 are one 16,384-element chunk of the flat form: same partial sums, same bits
+        assert torch.equal(wa, wb) and torch.equal(sa, sb)
+        assert torch.equal(oa.state[wa]["exp_avg"], ob.state[wb]["exp_avg"])
+        assert torch.equal(oa.state[wa]["exp_avg_sq"], ob.state[wb]["exp_avg_sq"])
+    else:            # the norm's partial sums are cut elsewhere: the clip factor differs in its last bits
+        _close(wa, wb)
+        _close(sa, sb)
+        _close(oa.state[wa]["exp_avg"], ob.state[wb]["exp_avg"])
+        _close(oa.state[wa]["exp_avg_sq"], ob.state[wb]["exp_avg_sq"])

@@ -24,7 +24,7 @@ def _both(n, n_rows, d, seed, with_types=False):
     want = torch.zeros(n_rows, d, device=DEV)
     ws = torch.empty(L.hmx_scatter_add_rows_workspace_bytes(n, n_rows, d), dtype=torch.uint8, device=DEV)
     hmx.check(L.hmx_scatter_add_rows_f32(hmx.ptr(rows_d), hmx.ptr(ids_d), hmx.ptr(tt_d), 1, n, d, hmx.ptr(want), n_rows, 0,
-                                         hmx.ptr(ws), ws.numel(), s), "hmx_scatter_add_rows_f32")
+                                         None, hmx.ptr(ws), ws.numel(), s), "hmx_scatter_add_rows_f32")
     got = torch.zeros(n_rows, d, device=DEV)
     hmx.check(L.hmx_scatter_add_rows_f32_static(hmx.ptr(rows_d), hmx.ptr(ids_d), hmx.ptr(tt_d), 1, n, d, hmx.ptr(got),
                                                 n_rows, 0, s), "hmx_scatter_add_rows_f32_static")
