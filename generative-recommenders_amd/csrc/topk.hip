@@ -670,6 +670,115 @@ __global__ __launch_bounds__(64, 2) void warm_threshold_kernel(CoarseParams p, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Start thresholds for launches of FEW queries with a LARGE k (the hard-negative miner: 1024 users, top-50, the pass
+// cut into 64 item splits).  Such a pass cannot start at -inf (every score is appended, every list compacted), and
+// growing exact prefix passes cost more than the pass itself.  Instead a strided sample of the table's tiles is
+// scored once with the MFMA tiles of the pass and NO lists: wave (query tile, split) keeps, per lane, the maximum of
+// its even and of its odd sampled tiles.  Every maximum belongs to a different row, so a query ends up with
+// 4 * n_splits scores of distinct rows; group_threshold_kernel turns them into a start value that at least k
+// ELIGIBLE rows reach (it knows the exact scores of the query's excluded ids).  Like every start value it is a
+// heuristic the result does not depend on: the re-score kernel's completeness proof decides.
+template <int KS>
+__global__ __launch_bounds__(64, 2) void group_max_kernel(CoarseParams p, int tiles_per_split, int tile_step,
+                                                          float* __restrict__ gmax) {
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    int qtile, split;
+    decode_wave(p, qtile, split);
+    short8 bq[KS];
+    const int64_t qrow = (int64_t)qtile * 32 + j;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bq[ks] = *reinterpret_cast<const short8*>(p.q_bf16 + qrow * p.dpad + 16 * ks + 8 * h);
+    // sampled tile i of this split is table tile (i * n_splits + split) * tile_step (all of them full tiles: host)
+    const uint16_t* ap = p.t_bf16 + ((int64_t)split * tile_step * 32 + j) * p.dpad + 8 * h;
+    const int64_t stride = 32 * (int64_t)p.dpad * tile_step * p.n_splits;
+    float best[2] = {kNegInf, kNegInf};
+    short8 a0[KS], a1[KS];
+    auto load_tile = [&](short8(&dst)[KS], int t) {
+        const uint16_t* src = ap + (int64_t)t * stride;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = *reinterpret_cast<const short8*>(src + 16 * ks);
+    };
+    auto score_tile = [&](const short8(&a)[KS], float& into) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bq[ks], acc, 0, 0, 0);
+        float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 3) m = fmaxf(m, fmaxf(fmaxf(acc[r], acc[r + 1]), acc[r + 2]));
+        into = fmaxf(into, fmaxf(m, acc[15]));
+    };
+    int t = 0;
+    if (tiles_per_split > 0) load_tile(a0, 0);
+    for (; t + 2 < tiles_per_split; t += 2) {       // even tiles feed best[0], odd ones best[1]
+        load_tile(a1, t + 1);
+        score_tile(a0, best[0]);
+        load_tile(a0, t + 2);
+        score_tile(a1, best[1]);
+    }
+    if (t < tiles_per_split) score_tile(a0, best[0]);
+    if (t + 1 < tiles_per_split) {
+        load_tile(a1, t + 1);
+        score_tile(a1, best[1]);
+    }
+    float* o = gmax + ((int64_t)qtile * 32 + j) * (4 * p.n_splits) + 4 * split + 2 * h;
+    o[0] = best[0];
+    o[1] = best[1];
+}
+
+// One wave per query: start threshold = the largest sampled maximum v such that (maxima >= v) - (excluded ids whose
+// exact score, plus the coarse error margin, reaches v) >= k; -inf when there is none.  Padded queries get +inf.
+__global__ __launch_bounds__(64) void group_threshold_kernel(const float* __restrict__ gmax, int n_groups,
+                                                             const float* __restrict__ q_f32, const float* __restrict__ t_f32,
+                                                             int64_t n_q, int64_t n_rows, int d, int k,
+                                                             const int64_t* __restrict__ exclude, int n_excl, int64_t id_offset,
+                                                             const float* __restrict__ max_row_norm,
+                                                             float* __restrict__ init_thr) {
+    constexpr int kMaxGroups = 256, kMaxExcl = 512;
+    __shared__ float sh_g[kMaxGroups];
+    __shared__ float sh_e[kMaxExcl];
+    const int lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    if (q >= n_q) {                 // wave-uniform
+        if (lane == 0) init_thr[q] = INFINITY;
+        return;
+    }
+    const float* qv = q_f32 + q * d;
+    for (int g = lane; g < n_groups; g += 64) sh_g[g] = gmax[q * n_groups + g];
+    const int ne = min(n_excl, kMaxExcl);
+    for (int e = lane; e < ne; e += 64) {
+        const int64_t row = exclude[q * n_excl + e] - id_offset;
+        float sc = kNegInf;
+        if (row >= 0 && row < n_rows) {
+            const float* tv = t_f32 + row * d;
+            sc = 0.f;
+            for (int c = 0; c < d; ++c) sc = __builtin_fmaf(qv[c], tv[c], sc);
+        }
+        sh_e[e] = sc;
+    }
+    float n2 = 0.f;
+    for (int c = lane; c < d; c += 64) n2 += qv[c] * qv[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
+    const float eps = 0.00398f * sqrtf(n2) * max_row_norm[0];
+    __syncthreads();
+    float best = kNegInf;
+    for (int g = lane; g < n_groups; g += 64) {
+        const float v = sh_g[g];
+        if (!(v > kNegInf)) continue;
+        int reach = 0, gone = 0;
+        for (int o = 0; o < n_groups; ++o) reach += (sh_g[o] >= v) ? 1 : 0;
+        for (int e = 0; e < ne; ++e) gone += (sh_e[e] + eps >= v) ? 1 : 0;
+        if (n_excl > kMaxExcl) gone += n_excl - kMaxExcl;         // ids that were not scored count as reaching v
+        if (reach - gone >= k) best = fmaxf(best, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    if (lane == 0) init_thr[q] = best > kNegInf ? best - fabsf(best) * 1e-6f - 1e-30f : kNegInf;
+}
+
 // fp32 MFMA: D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) per instruction, k0 on lanes 0-31, k1 on 32-63,
 // so stepping k by 2 reproduces the k-ordered fma chain bit for bit.
 template <int KP, bool EXCL>
@@ -1360,6 +1469,18 @@ int seed_levels(int64_t n_rows, int KP, int64_t* sample_rows) {
     return n;
 }
 
+// Every how-many-th tile of the table group_max_kernel samples (HMX_TOPK_GROUP_STEP overrides; 0 = keep the exact
+// prefix passes).
+int group_max_step() {
+    static const int step = [] {
+        const char* e = getenv("HMX_TOPK_GROUP_STEP");
+        if (e == nullptr) return 16;
+        const int v = atoi(e);
+        return (v >= 0 && v <= 1024) ? v : 16;
+    }();
+    return step;
+}
+
 // Launch shapes whose start thresholds are sampled (warm_threshold_kernel) or taken from the caller: top-16 or less
 // in at most four item splits, i.e. launches of 512 query tiles or more.  Every split starts from the query's one
 // sampled threshold.  Whole table, top-10, ms per launch seeded -> sampled: 131,072 queries (2 splits) 61.2 -> 54.5,
@@ -1530,7 +1651,43 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
             HMX_CHECK_LAUNCH();
             continue;
         }
-        for (int lvl = 0; lvl < tp.n_seed; ++lvl) {
+        // few queries, large k, split pass: one sampled no-list pass instead of the exact prefix passes
+        const int64_t gm_tiles = group_max_step() > 0 ? n_rows / 32 / (int64_t)group_max_step() : 0;
+        const int gm_tps = (int)std::min<int64_t>(gm_tiles / pl.n_splits, 1 << 20);
+        const bool group_seed = bf16 && tp.n_seed > 0 && pl.NB == 1 && pl.KP == 64 && group_max_step() > 0 && gm_tps >= 4 &&
+                                4 * pl.n_splits <= 256 && (size_t)rows_pad * 4 * pl.n_splits * sizeof(float) <= tp.cand_bytes &&
+                                sample_out == nullptr && ext_thr == nullptr;
+        if (group_seed) {
+            float* gmax = reinterpret_cast<float*>(cand);     // consumed before the pass below writes its lists there
+            CoarseParams gp{};
+            gp.q_bf16 = q_bf16;
+            gp.t_bf16 = table_bf16;
+            gp.dpad = pl.dpad;
+            gp.n_qtiles = n_qtiles;
+            gp.n_splits = pl.n_splits;
+            gp.debug_skip_publish = -1;
+            void* span = hmx_profile_begin("topk_seed_bf16", s);
+            if (pl.KS == 4)
+                hipLaunchKernelGGL(group_max_kernel<4>, dim3(n_qtiles * pl.n_splits), dim3(64), 0, s, gp, gm_tps,
+                                   group_max_step(), gmax);
+            else if (pl.KS == 8)
+                hipLaunchKernelGGL(group_max_kernel<8>, dim3(n_qtiles * pl.n_splits), dim3(64), 0, s, gp, gm_tps,
+                                   group_max_step(), gmax);
+            else if (pl.KS == 2)
+                hipLaunchKernelGGL(group_max_kernel<2>, dim3(n_qtiles * pl.n_splits), dim3(64), 0, s, gp, gm_tps,
+                                   group_max_step(), gmax);
+            else
+                hipLaunchKernelGGL(group_max_kernel<1>, dim3(n_qtiles * pl.n_splits), dim3(64), 0, s, gp, gm_tps,
+                                   group_max_step(), gmax);
+            hmx_profile_end(span, s);
+            HMX_CHECK_LAUNCH();
+            hipLaunchKernelGGL(group_threshold_kernel, dim3((unsigned)rows_pad), dim3(64), 0, s, gmax, 4 * pl.n_splits,
+                               queries + q0 * d, table, nq, n_rows, (int)d, (int)k, excl ? exclude + q0 * n_excl : nullptr,
+                               excl ? (int)n_excl : 0, id_offset, max_row_norm, init_thr);
+            HMX_CHECK_LAUNCH();
+            thr0 = init_thr;
+        }
+        for (int lvl = 0; lvl < (group_seed ? 0 : tp.n_seed); ++lvl) {
             // exact top-K of the prefix lands in the output buffers (overwritten by the next pass)
             const int rc = pass(tp.seed[lvl], tp.seed_rows[lvl], thr0, nullptr, "topk_seed_bf16");
             if (rc != HMX_OK) return rc;
