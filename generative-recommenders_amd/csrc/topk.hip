@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64) void group_threshold_kernel(const float* __rest
                                                              const int64_t* __restrict__ exclude, int n_excl, int64_t id_offset,
                                                              const float* __restrict__ max_row_norm,
                                                              float* __restrict__ init_thr) {
-    constexpr int kMaxGroups = 256, kMaxExcl = 512;
+    constexpr int kMaxGroups = 1024, kMaxExcl = 1024;
     __shared__ float sh_g[kMaxGroups];
     __shared__ float sh_e[kMaxExcl];
     const int lane = threadIdx.x;
@@ -1493,6 +1493,7 @@ struct TopkPlans {
     Plan seed[kMaxSeedLevels];
     int64_t seed_rows[kMaxSeedLevels];
     int n_seed;
+    bool want_seed;      // a split pass without sampled thresholds: it is seeded (group maxima, or the prefix passes)
     size_t cand_bytes, meta_bytes;
     size_t total() const { return full.q_bf16_bytes + full.thr_bytes + cand_bytes + 2 * meta_bytes + 2048; }
 };
@@ -1500,6 +1501,7 @@ struct TopkPlans {
 bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, TopkPlans& tp) {
     if (!make_plan(n_q, n_rows, d, k, bf16, tp.full)) return false;
     tp.n_seed = 0;
+    tp.want_seed = false;
     tp.cand_bytes = tp.full.cand_bytes;
     tp.meta_bytes = tp.full.meta_bytes;
     if (!bf16) return true;
@@ -1513,7 +1515,8 @@ bool make_plans(int64_t n_q, int64_t n_rows, int64_t d, int64_t k, bool bf16, To
         return e == nullptr || e[0] != '0';
     }();
     const bool sampled = sampled_start(tp.full);
-    const int n = (tp.full.n_splits >= 2 && !sampled && seed_on) ? seed_levels(n_rows, tp.full.KP, rows) : 0;
+    tp.want_seed = tp.full.n_splits >= 2 && !sampled && seed_on;
+    const int n = tp.want_seed ? seed_levels(n_rows, tp.full.KP, rows) : 0;
     for (int i = 0; i < n; ++i) {
         Plan ps;
         if (!make_plan(n_q, rows[i], d, k, true, ps) || ps.chunk != tp.full.chunk) {
@@ -1654,8 +1657,8 @@ int run_topk(bool bf16, const float* queries, int64_t n_q, const float* table, c
         // few queries, large k, split pass: one sampled no-list pass instead of the exact prefix passes
         const int64_t gm_tiles = group_max_step() > 0 ? n_rows / 32 / (int64_t)group_max_step() : 0;
         const int gm_tps = (int)std::min<int64_t>(gm_tiles / pl.n_splits, 1 << 20);
-        const bool group_seed = bf16 && tp.n_seed > 0 && pl.NB == 1 && pl.KP == 64 && group_max_step() > 0 && gm_tps >= 4 &&
-                                4 * pl.n_splits <= 256 && (size_t)rows_pad * 4 * pl.n_splits * sizeof(float) <= tp.cand_bytes &&
+        const bool group_seed = bf16 && tp.want_seed && pl.NB == 1 && pl.KP == 64 && group_max_step() > 0 && gm_tps >= 4 &&
+                                4 * pl.n_splits <= 1024 && (size_t)rows_pad * 4 * pl.n_splits * sizeof(float) <= tp.cand_bytes &&
                                 sample_out == nullptr && ext_thr == nullptr;
         if (group_seed) {
             float* gmax = reinterpret_cast<float*>(cand);     // consumed before the pass below writes its lists there
