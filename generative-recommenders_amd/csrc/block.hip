@@ -97,11 +97,13 @@ __device__ __forceinline__ void mma(f32x16& acc, const WSrc<LDSW>& src, size_t w
     const unsigned base = (unsigned)w + (unsigned)(nt * KS + ks) * 128u;      // wave-uniform
     uint4 e0, e1;
     if (LDSW && base >= src.lo && base < src.hi) {
-        e0 = w_lds[base - src.lo + lane];
-        e1 = w_lds[base - src.lo + 64 + lane];
+        const uint4* lp = w_lds + (base - src.lo);
+        e0 = lp[lane];
+        e1 = lp[64 + lane];
     } else {
-        e0 = src.g[base + lane];
-        e1 = src.g[base + 64 + lane];
+        const uint4* wp = src.g + base;      // wave-uniform base (scalar registers) + one per-lane offset for every load
+        e0 = wp[lane];
+        e1 = wp[64 + lane];
     }
     const short8 a_hi = __builtin_bit_cast(short8, e0);
     const short8 a_lo = __builtin_bit_cast(short8, e1);
@@ -127,6 +129,13 @@ __device__ __forceinline__ void store_tile(const f32x16& a, float* row, int nt, 
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(row + 32 * nt + 8 * q + 4 * h) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+
+// Sequence position of token 32 * tile + i.  The 64-bit remainder is taken once per wave on the tile's first token (scalar
+// unit); the lane's part is 32-bit.  Lanes past the last token get some valid position: their results are discarded.
+__device__ __forceinline__ int tile_pos(int64_t tile, int i, int L) {
+    const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)((tile * 32) % L));
+    return (int)((first + (unsigned)i) % (unsigned)L);
 }
 
 // sum of a per-lane value over the two lanes (l, l ^ 32) that share a token
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(256) void block_pre_fwd_kernel(BlockParams p) {
         const float rstd = norm1<NT>(p, p.x + tt * d, p.drop ? p.drop + tt * d : nullptr, h, xd, n);
         linear1<NT, LDSW>(p, src, n, p.mask ? p.mask[tt] : 1.f, h, lane, x1);
         // s = SiLU(x1) (kept in x1), y2 = RoPE(s): pairs (2 i, 2 i + 1) are registers (e, e + 1), e even
-        const int pos = (int)(tt % p.L);
+        const int pos = tile_pos(tile, i, p.L);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x16 y2;
@@ -539,6 +548,49 @@ __device__ __forceinline__ void write_scale_partial(const f32x16 (&acc)[NT], flo
         }
 }
 
+// Per-lane running sums of a backward half's scale gradient, one value per accumulator register of NT tiles.  In
+// registers up to d = 96; at d = 128 the 64 values per lane live in LDS instead (free there: the weights of that width
+// do not fit LDS and are read from L2), laid out [value][thread] so that a wave's accesses are conflict-free.
+template <int NT, bool IN_LDS>
+struct ColumnSums {
+    f32x16 reg[IN_LDS ? 1 : NT];
+    float* mine;
+    static constexpr int stride = 256;          // threads of a backward workgroup
+    __device__ __forceinline__ void init() {
+        if constexpr (IN_LDS) {
+            mine = reinterpret_cast<float*>(w_lds) + threadIdx.x;
+#pragma unroll
+            for (int v = 0; v < 16 * NT; ++v) mine[v * stride] = 0.f;
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) zero(reg[nt]);
+        }
+    }
+    __device__ __forceinline__ void add(int nt, const f32x16& v) {
+        if constexpr (IN_LDS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(16 * nt + r) * stride] += v[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) reg[nt][r] += v[r];
+        }
+    }
+    __device__ __forceinline__ void flush(float* part_row, int lane) {
+        if constexpr (IN_LDS) {
+            f32x16 all[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) all[nt][r] = mine[(16 * nt + r) * stride];
+            write_scale_partial<NT>(all, part_row, lane);
+        } else {
+            write_scale_partial<NT>(reg, part_row, lane);
+        }
+    }
+};
+constexpr bool sums_in_lds(int NT, bool LDSW) { return NT >= 4 && !LDSW; }
+constexpr size_t kSumsLdsBytes = 256 * 64 * sizeof(float);      // 256 threads x 64 values
+
 // Waves per workgroup of the backward halves.  Their working set wants more than 256 registers, i.e. one wave per SIMD.
 // Eight waves per workgroup (two per SIMD at 256 registers each, sharing one LDS copy of the weights) were measured
 // at d = 64: 216 / 316 bytes per lane spill to scratch and both halves get slower (post 172 -> 177 us, pre 123 -> 139 us
@@ -558,9 +610,8 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_post_bwd_kernel(Bloc
     }
     const int d = 32 * NT, C = l.H * l.ED;
     const int64_t n_tiles = hmx_ceil_div(p.T, 32);
-    f32x16 dsc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) zero(dsc[nt]);
+    ColumnSums<NT, sums_in_lds(NT, LDSW)> dsc;
+    dsc.init();
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         const int64_t t = tile * 32 + i;
         const bool ok = t < p.T;
@@ -641,14 +692,15 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_post_bwd_kernel(Bloc
         Frag dmf[2 * NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f32x16 mt, sc, dm;
+            f32x16 mt, sc, dm, dsv;
             load_tile(mt, p.m + tt * d, nt, h);
             load_tile(sc, p.scale2, nt, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                dsc[nt][r] += dn2[nt][r] * mt[r] * rstd2;                   // masked / padded tokens contribute dn2 = 0
+                dsv[r] = dn2[nt][r] * mt[r] * rstd2;                        // masked / padded tokens contribute dn2 = 0
                 dm[r] = rstd2 * (sc[r] * dn2[nt][r] - mt[r] * coef);
             }
+            dsc.add(nt, dsv);
             if (!p.first) {
                 f32x16 dot_;
                 load_tile(dot_, p.dout + tt * d, nt, h);
@@ -699,7 +751,7 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_post_bwd_kernel(Bloc
             }
         }
     }
-    write_scale_partial<NT>(dsc, p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
+    dsc.flush(p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
 }
 
 // ------------------------------------------------------------------ pre half, backward
@@ -715,23 +767,20 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_pre_bwd_kernel(Block
     }
     const int d = 32 * NT, C = l.H * l.ED;
     const int64_t n_tiles = hmx_ceil_div(p.T, 32);
-    f32x16 dsc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) zero(dsc[nt]);
+    ColumnSums<NT, sums_in_lds(NT, LDSW)> dsc;
+    dsc.init();
     for (int64_t tile = (int64_t)blockIdx.x * WPB + wave; tile < n_tiles; tile += (int64_t)gridDim.x * WPB) {
         const int64_t t = tile * 32 + i;
         const bool ok = t < p.T;
         const int64_t tt = ok ? t : p.T - 1;
         const float live = ok ? 1.f : 0.f;
         const float mk = p.mask ? p.mask[tt] : 1.f;
-        f32x16 xd[NT], n[NT], x1[NT];
-        const float rstd = norm1<NT>(p, p.x + tt * d, p.drop ? p.drop + tt * d : nullptr, h, xd, n);
-        linear1<NT, LDSW>(p, src, n, mk, h, lane, x1);
+        // Phases in the order that keeps the fewest tiles alive: the in_proj gradient first (its accumulators are all
+        // that lives through the long streaming loop), then the recomputation of n and x1, one x1 tile at a time.
         // ds = sum_heads Win_h^T [dx_in_h ; dz_h]
         f32x16 ds[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) zero(ds[nt]);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int hh = 0; hh < l.H; ++hh) {
             const size_t w = l.wint + hh * l.wint_stride;
@@ -753,12 +802,49 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_pre_bwd_kernel(Block
                 }
             }
         }
-        // + RoPE^T(dy2);  dx1 = ds * SiLU'(x1);  s = SiLU(x1)
-        const int pos = (int)(tt % p.L);
+        __builtin_amdgcn_sched_barrier(0);
+        // n = RMSNorm1(x * drop): written for the weight gradient of linear1 and kept as the fragments of n * mask.
+        // The tiles of x * drop stay in registers where the register file has room for them (d <= 64); wider blocks
+        // read x (and drop) again in the two places of the norm's backward that use them -- L1 / L2 hits.
+        constexpr bool kKeepXd = NT <= 2;
+        const float* xrow = p.x + tt * d;
+        const float* droprow = p.drop ? p.drop + tt * d : nullptr;
+        f32x16 xd[NT];
+        Frag nf[2 * NT];
+        float rstd;
+        {
+            f32x16 n[NT];
+            rstd = norm1<NT>(p, xrow, droprow, h, xd, n);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (ok) store_tile(n[nt], p.n + t * d, nt, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) n[nt][r] *= mk;
+                tile_frags(n[nt], nf[2 * nt], nf[2 * nt + 1]);
+            }
+        }
+        auto xd_tile = [&](int nt) -> f32x16 {
+            if constexpr (kKeepXd) return xd[nt];
+            f32x16 v;
+            load_tile(v, xrow, nt, h);
+            if (droprow != nullptr) {
+                f32x16 dr;
+                load_tile(dr, droprow, nt, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= dr[r];
+            }
+            return v;
+        };
+        if constexpr (!kKeepXd) __builtin_amdgcn_sched_barrier(0);
+        // x1 = W1 (n * mask) + b1 one tile at a time;  + RoPE^T(dy2);  dx1 = ds * SiLU'(x1);  s = SiLU(x1)
+        const int pos = tile_pos(tile, i, p.L);
         Frag d1f[2 * NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f32x16 g2, sv_, dx1;
+            f32x16 x1, g2, sv_, dx1;
+            load_tile(x1, p.b1, nt, h);
+#pragma unroll
+            for (int ks = 0; ks < 2 * NT; ++ks) mma<LDSW>(x1, src, l.w1, nt, 2 * NT, ks, nf[ks], lane);
             load_tile(g2, p.dy2 + tt * d, nt, h);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -770,60 +856,71 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_pre_bwd_kernel(Block
                 const float go0 = ds[nt][4 * q + 1] - g2[4 * q] * sn.x + g2[4 * q + 1] * c.x;
                 const float ge1 = ds[nt][4 * q + 2] + g2[4 * q + 2] * c.y + g2[4 * q + 3] * sn.y;
                 const float go1 = ds[nt][4 * q + 3] - g2[4 * q + 2] * sn.y + g2[4 * q + 3] * c.y;
-                dx1[4 * q] = ge0 * silu_grad_(x1[nt][4 * q]) * live;
-                dx1[4 * q + 1] = go0 * silu_grad_(x1[nt][4 * q + 1]) * live;
-                dx1[4 * q + 2] = ge1 * silu_grad_(x1[nt][4 * q + 2]) * live;
-                dx1[4 * q + 3] = go1 * silu_grad_(x1[nt][4 * q + 3]) * live;
+                dx1[4 * q] = ge0 * silu_grad_(x1[4 * q]) * live;
+                dx1[4 * q + 1] = go0 * silu_grad_(x1[4 * q + 1]) * live;
+                dx1[4 * q + 2] = ge1 * silu_grad_(x1[4 * q + 2]) * live;
+                dx1[4 * q + 3] = go1 * silu_grad_(x1[4 * q + 3]) * live;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sv_[r] = silu_(x1[nt][r]);
+            for (int r = 0; r < 16; ++r) sv_[r] = silu_(x1[r]);
             if (ok) {
                 store_tile(sv_, p.s + t * d, nt, h);
                 store_tile(dx1, p.dx1 + t * d, nt, h);
-                store_tile(n[nt], p.n + t * d, nt, h);
             }
             tile_frags(dx1, d1f[2 * nt], d1f[2 * nt + 1]);
+            if constexpr (!kKeepXd) __builtin_amdgcn_sched_barrier(0);      // one tile's weight loads in flight at a time
         }
         // dn = (W1^T dx1) * mask (+ dm in the first block: m = n + ...);  RMSNorm1 backward;  dx = dxd * drop + c dm
-        f32x16 dn[NT], sc1[NT], dmv[NT];
+        f32x16 dn[NT];
         float dot = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             zero(dn[nt]);
 #pragma unroll
             for (int ks = 0; ks < 2 * NT; ++ks) mma<LDSW>(dn[nt], src, l.w1t, nt, 2 * NT, ks, d1f[ks], lane);
-            load_tile(dmv[nt], p.dm + tt * d, nt, h);
-            load_tile(sc1[nt], p.scale1, nt, h);
+            f32x16 sc1;
+            load_tile(sc1, p.scale1, nt, h);
+            const f32x16 xv = xd_tile(nt);
+            if (p.first) {
+                f32x16 dmv;
+                load_tile(dmv, p.dm + tt * d, nt, h);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dmv[nt][r] *= live;
-                dn[nt][r] = dn[nt][r] * mk + (p.first ? dmv[nt][r] : 0.f);
-                dot += dn[nt][r] * sc1[nt][r] * xd[nt][r];
+                for (int r = 0; r < 16; ++r) dn[nt][r] = dn[nt][r] * mk + dmv[r] * live;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dn[nt][r] *= mk;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot += dn[nt][r] * sc1[r] * xv[r];
+            if constexpr (!kKeepXd) __builtin_amdgcn_sched_barrier(0);
         }
         dot = pair_sum(dot);
         const float coef = dot * rstd * rstd * p.inv_d;
         const float cres = p.first ? 1.f : 2.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f32x16 dxv;
+            f32x16 dxv, sc1, dmv, dsv;
+            load_tile(sc1, p.scale1, nt, h);
+            load_tile(dmv, p.dm + tt * d, nt, h);
+            const f32x16 xv = xd_tile(nt);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                dsc[nt][r] += dn[nt][r] * xd[nt][r] * rstd;
-                dxv[r] = rstd * (sc1[nt][r] * dn[nt][r] - xd[nt][r] * coef);
+                dsv[r] = dn[nt][r] * xv[r] * rstd;
+                dxv[r] = rstd * (sc1[r] * dn[nt][r] - xv[r] * coef);
             }
-            if (p.drop != nullptr) {
+            dsc.add(nt, dsv);
+            if (droprow != nullptr) {
                 f32x16 dr;
-                load_tile(dr, p.drop + tt * d, nt, h);
+                load_tile(dr, droprow, nt, h);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dxv[r] *= dr[r];
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dxv[r] += cres * dmv[nt][r];
+            for (int r = 0; r < 16; ++r) dxv[r] += cres * dmv[r] * live;
             if (ok) store_tile(dxv, p.dx + t * d, nt, h);
         }
     }
-    write_scale_partial<NT>(dsc, p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
+    dsc.flush(p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
 }
 
 // workgroups of a launch whose workgroups hold `waves` waves (one 32-token tile per wave and trip)
@@ -843,29 +940,32 @@ constexpr size_t kMaxWeightLds = 128 * 1024;
 // (the copy is paid once per CU: one workgroup per CU walks the token tiles); otherwise weights come from L2.
 // Measured at d = 64: the backward halves (512 registers, one wave per SIMD either way) gain 7-10 % from LDS weights;
 // the forward halves fit two waves per SIMD without the LDS footprint and are faster that way, so they pass lo = hi.
-#define HMX_BLOCK_LAUNCH(KERNEL, NTV, WAVES, p, T, lo, hi, stream)                                                   \
+#define HMX_BLOCK_LAUNCH(KERNEL, NTV, WAVES, BWD, p, T, lo, hi, stream)                                                   \
     do {                                                                                                             \
         const size_t lds_bytes = ((hi) - (lo)) * sizeof(uint4);                                                      \
-        if ((hi) > (lo) && lds_bytes <= kMaxWeightLds) {                                                             \
+        constexpr bool kCanLds = (NTV) < 4;      /* one d = 128 weight image is 64 KB: no useful range fits */        \
+        if (kCanLds && (hi) > (lo) && lds_bytes <= kMaxWeightLds) {                                                  \
             (p).lds_lo = (unsigned)(lo);                                                                             \
             (p).lds_hi = (unsigned)(hi);                                                                             \
-            hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&KERNEL<NTV, true>), (int)kMaxWeightLds);            \
-            hipLaunchKernelGGL((KERNEL<NTV, true>), dim3(std::min(block_grid(T, WAVES), 256)), dim3(64 * (WAVES)),   \
+            hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&KERNEL<NTV, kCanLds>), (int)kMaxWeightLds);         \
+            hipLaunchKernelGGL((KERNEL<NTV, kCanLds>), dim3(std::min(block_grid(T, WAVES), 256)), dim3(64 * (WAVES)), \
                                lds_bytes, stream, p);                                                                \
         } else {                                                                                                     \
             (p).lds_lo = (p).lds_hi = 0;                                                                             \
+            const size_t sums_bytes = (BWD) && sums_in_lds(NTV, false) ? kSumsLdsBytes : 0;                          \
+            if (sums_bytes) hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&KERNEL<NTV, false>), (int)sums_bytes); \
             hipLaunchKernelGGL((KERNEL<NTV, false>), dim3(std::min(block_grid(T, WAVES), 4096 / (WAVES))),           \
-                               dim3(64 * (WAVES)), 0, stream, p);                                                    \
+                               dim3(64 * (WAVES)), sums_bytes, stream, p);                                           \
         }                                                                                                            \
     } while (0)
 
 // BWD: the kernel is a backward half (bwd_waves(NT) waves per workgroup); forward halves have four
 #define HMX_BLOCK_DISPATCH(KERNEL, BWD, p, lo, hi, stream)                                                           \
     switch ((p).lay.NT) {                                                                                            \
-        case 1: HMX_BLOCK_LAUNCH(KERNEL, 1, (BWD) ? bwd_waves(1) : 4, p, (p).T, lo, hi, stream); break;              \
-        case 2: HMX_BLOCK_LAUNCH(KERNEL, 2, (BWD) ? bwd_waves(2) : 4, p, (p).T, lo, hi, stream); break;              \
-        case 3: HMX_BLOCK_LAUNCH(KERNEL, 3, (BWD) ? bwd_waves(3) : 4, p, (p).T, lo, hi, stream); break;              \
-        default: HMX_BLOCK_LAUNCH(KERNEL, 4, (BWD) ? bwd_waves(4) : 4, p, (p).T, lo, hi, stream); break;             \
+        case 1: HMX_BLOCK_LAUNCH(KERNEL, 1, (BWD) ? bwd_waves(1) : 4, BWD, p, (p).T, lo, hi, stream); break;              \
+        case 2: HMX_BLOCK_LAUNCH(KERNEL, 2, (BWD) ? bwd_waves(2) : 4, BWD, p, (p).T, lo, hi, stream); break;              \
+        case 3: HMX_BLOCK_LAUNCH(KERNEL, 3, (BWD) ? bwd_waves(3) : 4, BWD, p, (p).T, lo, hi, stream); break;              \
+        default: HMX_BLOCK_LAUNCH(KERNEL, 4, (BWD) ? bwd_waves(4) : 4, BWD, p, (p).T, lo, hi, stream); break;             \
     }
 
 }  // namespace
