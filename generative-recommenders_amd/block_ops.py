@@ -101,13 +101,13 @@ def _scale_grad(part):
 
 
 def _square_jobs(lay, pi, dy, x, mask, T, bi=None):
-    """Weight-gradient jobs of a (d, d) projection whose operands dy, x are (T, dp): one job when nothing is widened,
-    else one per pair of heads (the true hd x hd sub-block of the weight; the bias rides with the first column block)."""
+    """Weight-gradient job of a (d, d) projection whose operands dy, x are (T, dp).  Widened operands are read as they
+    are (whole aligned rows); the product's outputs map to the true weight by head groups (hdp columns, hd of them
+    real)."""
     if not lay.widened:
         return [(pi, dy, 0, lay.d, x, 0, lay.d, mask, T, lay.d, lay.d, 0, lay.d, bi, 0)]
     hd, hdp, d, dp = lay.hd, lay.hdp, lay.d, lay.dp
-    return [(pi, dy, g * hdp, dp, x, k * hdp, dp, mask, T, hd, hd, g * hd * d + k * hd, d, bi if k == 0 else None, g * hd)
-            for g in range(lay.H) for k in range(lay.H)]
+    return [(pi, dy, 0, dp, x, 0, dp, mask, T, dp, dp, 0, d, bi, 0, (hd, hdp, hd, hdp))]
 
 
 def _weight_grads(jobs, params, device):
@@ -117,7 +117,9 @@ def _weight_grads(jobs, params, device):
     needed)."""
     grads = [None] * len(params)
     immediate, descs, keep = [], [], []
-    for (pi, dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, dw_off, ldw, bi, db_off) in jobs:
+    for job in jobs:
+        (pi, dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, dw_off, ldw, bi, db_off), groups = job[:15], tuple(job[15:16])
+        groups = groups[0] if groups else (0, 0, 0, 0)
         q = params[pi]
         if q is None or not q.requires_grad:
             continue
@@ -126,20 +128,20 @@ def _weight_grads(jobs, params, device):
         tw = E._param_grad_target(q)
         tb = E._param_grad_target(bq) if want_b else None
         if tw is not None and (tb is not None or not want_b):
-            E._wgrad_queue.add(dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, tw, dw_off, ldw, tb, db_off)
+            E._wgrad_queue.add(dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, tw, dw_off, ldw, tb, db_off, groups)
             continue
         if grads[pi] is None:
             grads[pi] = torch.zeros_like(q, memory_format=torch.contiguous_format)
         if want_b and grads[bi] is None:
             grads[bi] = torch.zeros_like(bq)
         immediate.append((dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, grads[pi], dw_off, ldw, grads[bi] if want_b else None,
-                          db_off))
+                          db_off, groups))
     if immediate:
-        for (dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, dw, dw_off, ldw, db, db_off) in immediate:
+        for (dy, dy_off, ldy, x, x_off, ldx, mask, T, N, K, dw, dw_off, ldw, db, db_off, groups) in immediate:
             descs.append(hmx.WgradDesc(dy.data_ptr() + 4 * dy_off, ldy, x.data_ptr() + 4 * x_off, ldx,
                                        mask.data_ptr() if mask is not None else None, T, N, K,
                                        dw.data_ptr() + 4 * dw_off, ldw,
-                                       db.data_ptr() + 4 * db_off if db is not None else None, 1))
+                                       db.data_ptr() + 4 * db_off if db is not None else None, 1, *groups))
         for i in range(0, len(descs), 24):
             chunk = descs[i:i + 24]
             arr = (hmx.WgradDesc * len(chunk))(*chunk)

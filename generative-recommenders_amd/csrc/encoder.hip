@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
 }
 
 // ---------------------------------------------------------------------------- weight gradient (fp32 MFMA)
-// part[s][n][k] = sum_{t in split s} dY[t][n] * X[t][k] * in_rowmask[t];  column K (if with_bias) = sum_t dY[t][n].
+// dW[n][k] (+)= sum_t dY[t][n] * X[t][k] * in_rowmask[t];  dbias[n] (+)= sum_t dY[t][n].
 // One weight-gradient product of a batched launch.
 struct WgradJob {
     const float* dY;
@@ -403,172 +403,288 @@ struct WgradJob {
     float* dW;
     float* dbias;
     int64_t ldy, ldx, ldw, T;
+    int64_t slab0;           // first float of this job's slabs in the workspace
     int N, K, with_bias, accumulate;
-    int tile0;               // first global tile of this job
+    int tile0;               // first global macro tile of this job
+    int tn, tk;              // macro tile: (32 tn) x (32 tk) outputs per wave
+    int n_grp, n_grpp, k_grp, k_grpp;   // grouped outputs (0: plain), see hmx_wgrad_desc
 };
 constexpr int kWgradMaxJobs = 24;
 struct WgradParams {
     WgradJob job[kWgradMaxJobs];
     int n_jobs;
-    float* part;             // slabs [global tile][group][16 x 64]
-    unsigned* tickets;       // one arrival counter per global tile, zero on entry and on exit
+    float* part;             // slabs [job][macro tile][group][tn * tk tile images of 16 x 64, 128 bias sums]
+    unsigned* tickets;       // one arrival counter per global macro tile, zero on entry and on exit
 };
 
-// Arrival counters of the in-launch reduction below: one word per output tile of a launch, in a slot chosen by the
+// Arrival counters of the in-launch reduction below: one word per macro tile of a launch, in a slot chosen by the
 // host per call.  They are zero whenever no launch is in flight: the workgroup that arrives last puts its counter
 // back to zero.  (A slot belongs to one stream of one GPU at a time, see wgrad_tickets_for_call.)
 constexpr int kWgradMaxTiles = 1024;
 constexpr int kWgradSlots = 16;
 __device__ unsigned g_wgrad_tickets[kWgradSlots * kWgradMaxTiles];
 
-// Weight gradients of up to kWgradMaxJobs projections in one launch.  blockIdx.y walks the 32 x 32 output tiles of
-// all jobs, blockIdx.x the token-split groups.  One workgroup = four waves = four consecutive token splits of ONE
-// tile.  A wave runs trips of kSteps MFMA steps (2 tokens each) with the loads of the next trip issued before the
-// MFMAs of this one.  The four partial tiles are added in LDS (wave order) and written as one slab; the workgroup
-// that arrives last at the tile's counter adds the slabs in group order and writes (or adds to) dW / dbias: fixed
-// association order, no float atomics, no second launch.
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
-    __shared__ float sh[4][16][64];
-    __shared__ unsigned sh_ticket;
+constexpr int kWgradBiasFloats = 128;      // bias partial sums at the end of a slab (32 * tn <= 128)
+__host__ __device__ constexpr int64_t wgrad_slab_floats(int tn, int tk) { return (int64_t)tn * tk * 1024 + kWgradBiasFloats; }
+
+template <int V>
+__device__ __forceinline__ void wgrad_load(float (&dst)[V], const float* src) {
+    if constexpr (V == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    } else if constexpr (V == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(src);
+        dst[0] = v.x; dst[1] = v.y;
+    } else {
+        dst[0] = *src;
+    }
+}
+
+struct WgradShared {
+    float tile[4][16][64];
+    float bias[4][kWgradBiasFloats];
+    unsigned ticket;
+};
+
+// One macro tile of one job: a wave owns TN x TK accumulator tiles of 32 x 32 and one token split.  Lane (i, h)
+// supplies, for token 2 u + h of a step, TN consecutive columns of dY and TK consecutive columns of X with ONE vector
+// load each: accumulator tile (a, b) row i is output row n0 + TN i + a, column i is k0 + TK i + b.  Every operand
+// element is read once per macro tile instead of once per 32 x 32 tile, which is what bounds this kernel: the operands
+// of a launch do not fit L2, so each re-read comes from HBM.  The bias sum rides on the dY values in the vector unit.
+template <int TN, int TK>
+__device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const WgradJob& jb, int gtile, WgradShared& sh) {
+    constexpr int kSteps = TN * TK >= 8 ? 4 : 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
-    const int gtile = blockIdx.y;
-    int ji = 0;
-    while (ji + 1 < p.n_jobs && p.job[ji + 1].tile0 <= gtile) ++ji;     // wave-uniform scan of at most 24 entries
-    const WgradJob& jb = p.job[ji];
-    const int tile = gtile - jb.tile0;
-    const int kx = jb.K + (jb.with_bias ? 1 : 0);
-    const int kt_n = (kx + 31) / 32;
-    const int nt = tile / kt_n, kt = tile % kt_n;
-    const int n = nt * 32 + i, kc = kt * 32 + i;
+    const int mtile = gtile - jb.tile0;
+    const int mk_n = (jb.K + 32 * TK - 1) / (32 * TK);
+    const int n0 = (mtile / mk_n) * 32 * TN, k0 = (mtile % mk_n) * 32 * TK;
+    const int n = n0 + TN * i, k = k0 + TK * i;
+    const bool n_ok = n < jb.N, k_ok = k < jb.K;       // N % TN == 0 and K % TK == 0: a lane's vector is all in or all out
     const int n_groups = gridDim.x;
     int64_t tps = hmx_ceil_div(jb.T, (int64_t)n_groups * 4);
     tps += tps & 1;
     const int64_t t0 = min(jb.T, ((int64_t)blockIdx.x * 4 + wave) * tps);
     const int64_t t1 = min(jb.T, t0 + tps);
-    f32x16 acc;
+    f32x16 acc[TN][TK];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool n_ok = n < jb.N;
-    const int kind = kc < jb.K ? 0 : ((kc == jb.K && jb.with_bias) ? 1 : 2);
-    constexpr int kSteps = 8;
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[TN];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) bsum[a] = 0.f;
     const float* ap = jb.dY + (n_ok ? n : 0);
-    const float* bp = jb.X + (kind == 0 ? kc : 0);
+    const float* bp = jb.X + (k_ok ? k : 0);
     const float* mp = jb.in_rowmask;
     const int64_t ldy = jb.ldy, ldx = jb.ldx;
-    auto load_trip = [&](float(&a)[kSteps], float(&b)[kSteps], int64_t t) {   // tokens t .. t + 2 kSteps - 1, all < t1
+    auto load_trip = [&](float(&av)[kSteps][TN], float(&bv)[kSteps][TK], int64_t t) {   // tokens t .. t + 2 kSteps - 1 < t1
 #pragma unroll
         for (int u = 0; u < kSteps; ++u) {
             const int64_t tt = t + 2 * u + h;
-            a[u] = ap[tt * ldy];
-            b[u] = bp[tt * ldx];
+            wgrad_load<TN>(av[u], ap + tt * ldy);
+            wgrad_load<TK>(bv[u], bp + tt * ldx);
         }
         if (mp != nullptr) {
 #pragma unroll
-            for (int u = 0; u < kSteps; ++u) b[u] *= mp[t + 2 * u + h];
-        }
-    };
-    auto mfma_trip = [&](const float(&a)[kSteps], const float(&b)[kSteps]) {
+            for (int u = 0; u < kSteps; ++u) {
+                const float m = mp[t + 2 * u + h];
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(n_ok ? a[u] : 0.f, kind == 0 ? b[u] : (kind == 1 ? 1.f : 0.f), acc, 0, 0, 0);
-    };
-    int64_t t = t0;
-    const int64_t n_trips = (t1 - t0) / (2 * kSteps);
-    if (n_trips > 0) {
-        float a0[kSteps], b0[kSteps], a1[kSteps], b1[kSteps];
-        load_trip(a0, b0, t);
-        int64_t trip = 0;
-        for (; trip + 2 < n_trips; trip += 2) {     // both buffers reloaded unconditionally inside the loop
-            load_trip(a1, b1, t + 2 * kSteps);
-            mfma_trip(a0, b0);
-            load_trip(a0, b0, t + 4 * kSteps);
-            mfma_trip(a1, b1);
-            t += 4 * kSteps;
-        }
-        if (trip + 1 < n_trips) {                   // two trips left
-            load_trip(a1, b1, t + 2 * kSteps);
-            mfma_trip(a0, b0);
-            mfma_trip(a1, b1);
-            t += 4 * kSteps;
-        } else {                                    // one trip left
-            mfma_trip(a0, b0);
-            t += 2 * kSteps;
-        }
-    }
-    for (; t < t1; t += 2) {
-        const int64_t tt = t + h;
-        const bool ok = tt < t1;
-        const float a = (ok && n_ok) ? jb.dY[tt * ldy + n] : 0.f;
-        float b = 0.f;
-        if (ok) {
-            if (kind == 0) {
-                b = jb.X[tt * ldx + kc];
-                if (mp) b *= mp[tt];
-            } else if (kind == 1) {
-                b = 1.f;
+                for (int b = 0; b < TK; ++b) bv[u][b] *= m;
             }
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    // the four waves' tiles, added in wave order
+    };
+    auto mfma_step = [&](const float(&av)[TN], const float(&bv)[TK]) {
+        float az[TN], bz[TK];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sh[wave][r][lane] = acc[r];
-    __syncthreads();
-    const int e0 = threadIdx.x * 4;              // this thread's four consecutive elements of the [16][64] tile image
-    const float* s0 = &sh[0][0][0] + e0;
-    float4 v = *reinterpret_cast<const float4*>(s0);
+        for (int a = 0; a < TN; ++a) {
+            az[a] = n_ok ? av[a] : 0.f;
+            bsum[a] += az[a];
+        }
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-        const float4 o = *reinterpret_cast<const float4*>(s0 + w * 1024);
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        for (int b = 0; b < TK; ++b) bz[b] = k_ok ? bv[b] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[a], bz[b], acc[a][b], 0, 0, 0);
+    };
+    auto mfma_trip = [&](const float(&av)[kSteps][TN], const float(&bv)[kSteps][TK]) {
+#pragma unroll
+        for (int u = 0; u < kSteps; ++u) mfma_step(av[u], bv[u]);
+    };
+    // Trips of kSteps steps through a ring of kRing operand buffers: the loads of trip j + kRing - 1 are issued before
+    // the MFMAs of trip j, so two further trips are in flight while one is consumed (HBM latency under load is several
+    // trips long).  The ring index is static: the loop body is kRing stages.  Loads past the last trip repeat the last
+    // trip (in bounds, never consumed).
+    constexpr int kRing = 3;
+    const int64_t n_trips = (t1 - t0) / (2 * kSteps);
+    if (n_trips > 0) {
+        float av[kRing][kSteps][TN], bv[kRing][kSteps][TK];
+        const int64_t last = n_trips - 1;
+#pragma unroll
+        for (int s = 0; s < kRing - 1; ++s) load_trip(av[s], bv[s], t0 + min((int64_t)s, last) * (2 * kSteps));
+        for (int64_t trip = 0; trip < n_trips; trip += kRing) {
+#pragma unroll
+            for (int s = 0; s < kRing; ++s) {
+                load_trip(av[(s + kRing - 1) % kRing], bv[(s + kRing - 1) % kRing],
+                          t0 + min(trip + s + kRing - 1, last) * (2 * kSteps));
+                if (trip + s < n_trips) mfma_trip(av[s], bv[s]);
+            }
+        }
     }
-    float4* slabs = reinterpret_cast<float4*>(p.part) + (int64_t)gtile * n_groups * 256;
-    auto finish = [&](const float4& tot) {       // element e = r * 64 + lane_e of the tile image -> (n, k)
+    int64_t t = t0 + n_trips * (2 * kSteps);
+    for (; t < t1; t += 2) {                        // the split's last tokens, one step at a time
+        const int64_t tt = t + h;
+        const bool ok = tt < t1;
+        const int64_t tc = ok ? tt : t;             // t < t1: a valid row
+        float av[TN], bv[TK];
+        wgrad_load<TN>(av, ap + tc * ldy);
+        wgrad_load<TK>(bv, bp + tc * ldx);
+        const float m = ok ? (mp ? mp[tc] : 1.f) : 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) av[a] = ok ? av[a] : 0.f;
+#pragma unroll
+        for (int b = 0; b < TK; ++b) bv[b] *= m;
+        mfma_step(av, bv);
+    }
+    // Output of element e = r * 64 + lane_e of tile image (a, b)
+    auto finish = [&](const float4& tot, int a, int b) {
+        const int e0 = threadIdx.x * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = e0 + q, r = e >> 6, le = e & 63;
-            const int nr = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (le >> 5), kk = kt * 32 + (le & 31);
+            int nr = n0 + TN * ((r & 3) + 8 * (r >> 2) + 4 * (le >> 5)) + a, kk = k0 + TK * (le & 31) + b;
             const float val = q == 0 ? tot.x : q == 1 ? tot.y : q == 2 ? tot.z : tot.w;
-            if (nr < jb.N) {
-                float* dst = kk < jb.K ? jb.dW + (int64_t)nr * jb.ldw + kk : ((kk == jb.K && jb.with_bias) ? jb.dbias + nr : nullptr);
-                if (dst != nullptr) *dst = jb.accumulate ? *dst + val : val;
+            bool ok = nr < jb.N && kk < jb.K;
+            if (jb.n_grpp > 0) {
+                const int g = nr / jb.n_grpp, w = nr % jb.n_grpp;
+                ok = ok && w < jb.n_grp;
+                nr = g * jb.n_grp + w;
+            }
+            if (jb.k_grpp > 0) {
+                const int g = kk / jb.k_grpp, w = kk % jb.k_grpp;
+                ok = ok && w < jb.k_grp;
+                kk = g * jb.k_grp + w;
+            }
+            if (ok) {
+                float* dst = jb.dW + (int64_t)nr * jb.ldw + kk;
+                *dst = jb.accumulate ? *dst + val : val;
             }
         }
     };
-    if (n_groups == 1) {
-        finish(v);
-        return;
+    auto finish_bias = [&](float val) {             // thread a * 32 + i owns output row n0 + TN i + a
+        const int a = threadIdx.x >> 5, ii = threadIdx.x & 31;
+        int nr = n0 + TN * ii + a;
+        bool ok = nr < jb.N;
+        if (jb.n_grpp > 0) {
+            const int g = nr / jb.n_grpp, w = nr % jb.n_grpp;
+            ok = ok && w < jb.n_grp;
+            nr = g * jb.n_grp + w;
+        }
+        if (ok) jb.dbias[nr] = jb.accumulate ? jb.dbias[nr] + val : val;
+    };
+    const bool bias_here = jb.with_bias && k0 == 0;
+    const int64_t slab_f = wgrad_slab_floats(TN, TK);
+    float* slabs = p.part + jb.slab0 + (int64_t)mtile * n_groups * slab_f;     // [group][slab] of this macro tile
+    float* my_slab = slabs + (int64_t)blockIdx.x * slab_f;
+    // the four waves' tiles, added in wave order, one tile image at a time
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TK; ++b) {
+            if (a + b > 0) __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sh.tile[wave][r][lane] = acc[a][b][r];
+            __syncthreads();
+            const float* s0 = &sh.tile[0][0][0] + threadIdx.x * 4;
+            float4 v = *reinterpret_cast<const float4*>(s0);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 o = *reinterpret_cast<const float4*>(s0 + w * 1024);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if (n_groups == 1) finish(v, a, b);
+            else reinterpret_cast<float4*>(my_slab)[(a * TK + b) * 256 + threadIdx.x] = v;
+        }
+    if (bias_here) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const float s = bsum[a] + __shfl_xor(bsum[a], 32);
+            if (h == 0) sh.bias[wave][a * 32 + i] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 32 * TN) {
+            const float s = ((sh.bias[0][threadIdx.x] + sh.bias[1][threadIdx.x]) + sh.bias[2][threadIdx.x]) + sh.bias[3][threadIdx.x];
+            if (n_groups == 1) finish_bias(s);
+            else my_slab[TN * TK * 1024 + threadIdx.x] = s;
+        }
     }
-    slabs[(int64_t)blockIdx.x * 256 + threadIdx.x] = v;
+    if (n_groups == 1) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sh_ticket = __hip_atomic_fetch_add(p.tickets + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.ticket = __hip_atomic_fetch_add(p.tickets + gtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (sh_ticket != (unsigned)(n_groups - 1)) return;
+    if (sh.ticket != (unsigned)(n_groups - 1)) return;
     if (threadIdx.x == 0) {
         __hip_atomic_store(p.tickets + gtile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-    int g = 0;
-    for (; g + 8 <= n_groups; g += 8) {          // eight slabs requested together, added in group order
-        float4 o[8];
+    // last to arrive: the slabs of every group, added in group order
+#pragma unroll 1
+    for (int ab = 0; ab < TN * TK; ++ab) {
+        const float4* src = reinterpret_cast<const float4*>(slabs) + ab * 256 + threadIdx.x;
+        const int64_t stride = slab_f / 4;
+        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+        int g = 0;
+        for (; g + 8 <= n_groups; g += 8) {          // eight slabs requested together
+            float4 o[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) o[u] = slabs[(int64_t)(g + u) * 256 + threadIdx.x];
+            for (int u = 0; u < 8; ++u) o[u] = src[(int64_t)(g + u) * stride];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { tot.x += o[u].x; tot.y += o[u].y; tot.z += o[u].z; tot.w += o[u].w; }
+            for (int u = 0; u < 8; ++u) { tot.x += o[u].x; tot.y += o[u].y; tot.z += o[u].z; tot.w += o[u].w; }
+        }
+        for (; g < n_groups; ++g) {
+            const float4 o = src[(int64_t)g * stride];
+            tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
+        }
+        finish(tot, ab / TK, ab % TK);
     }
-    for (; g < n_groups; ++g) {
-        const float4 o = slabs[(int64_t)g * 256 + threadIdx.x];
-        tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
+    if (bias_here && threadIdx.x < 32 * TN) {
+        float tot = 0.f;
+        for (int g = 0; g < n_groups; ++g) tot += slabs[(int64_t)g * slab_f + TN * TK * 1024 + threadIdx.x];
+        finish_bias(tot);
     }
-    finish(tot);
+}
+
+// Weight gradients of up to kWgradMaxJobs projections in one launch.  blockIdx.y walks the macro tiles of all jobs,
+// blockIdx.x the token-split groups.  One workgroup = four waves = four consecutive token splits of ONE macro tile.  A
+// wave runs trips of MFMA steps (2 tokens each) with the loads of the next trip issued before the MFMAs of this one.
+// The four partial results are added in LDS (wave order) and written as one slab; the workgroup that arrives last at
+// the tile's counter adds the slabs in group order and writes (or adds to) dW / dbias: fixed association order, no
+// float atomics, no second launch.
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
+    __shared__ WgradShared sh;
+    const int gtile = blockIdx.y;
+    int ji = 0;
+    while (ji + 1 < p.n_jobs && p.job[ji + 1].tile0 <= gtile) ++ji;     // wave-uniform scan of at most 24 entries
+    const WgradJob& jb = p.job[ji];
+    switch (jb.tn * 8 + jb.tk) {
+        case 4 * 8 + 2: wgrad_macro_tile<4, 2>(p, jb, gtile, sh); break;
+        case 2 * 8 + 4: wgrad_macro_tile<2, 4>(p, jb, gtile, sh); break;
+        case 4 * 8 + 1: wgrad_macro_tile<4, 1>(p, jb, gtile, sh); break;
+        case 1 * 8 + 4: wgrad_macro_tile<1, 4>(p, jb, gtile, sh); break;
+        case 2 * 8 + 2: wgrad_macro_tile<2, 2>(p, jb, gtile, sh); break;
+        case 2 * 8 + 1: wgrad_macro_tile<2, 1>(p, jb, gtile, sh); break;
+        case 1 * 8 + 2: wgrad_macro_tile<1, 2>(p, jb, gtile, sh); break;
+        default: wgrad_macro_tile<1, 1>(p, jb, gtile, sh); break;
+    }
 }
 
 // ---------------------------------------------------------------------------- pointwise kernels
@@ -1258,15 +1374,44 @@ extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64
     return HMX_OK;
 }
 
-// Token splits of a weight-gradient launch: four per workgroup (one per wave), enough workgroups to put about two
-// thousand waves on the chip, at least 64 tokens per wave.
+// Token splits of a weight-gradient launch: four per workgroup (one per wave).  Two workgroups fit a CU, so the chip
+// runs 512 at a time, and the workgroups of a launch take about equally long: a grid of 528 would run as two rounds
+// of which the second is nearly empty.  Hence as many groups as keep groups x tiles within ONE round (launches with
+// more tiles than that run in several rounds of one group), at least 64 tokens per wave.
+constexpr int64_t kWgradResident = 512;
 static int64_t wgrad_groups(int64_t T_max, int64_t tiles) {
-    int64_t g = hmx_ceil_div(hmx_ceil_div(2048, tiles), 4);
+    int64_t g = std::max<int64_t>(1, kWgradResident / std::max<int64_t>(tiles, 1));
     g = std::min<int64_t>(g, hmx_ceil_div(T_max, 4 * 64));
     return std::max<int64_t>(1, std::min<int64_t>(g, 128));
 }
-static int64_t wgrad_tiles(int64_t N, int64_t K, bool with_bias) {
-    return hmx_ceil_div(N, 32) * hmx_ceil_div(K + (with_bias ? 1 : 0), 32);
+
+// Macro tile of a product: as many 32-wide tiles along N and K as vector loads allow (a lane reads tn consecutive
+// columns of dY and tk of X, so base, row stride and extent must be multiples of the vector), eight accumulators at most.
+struct WgradShape {
+    int tn, tk;
+    int64_t tiles;
+};
+static WgradShape wgrad_shape(const hmx_wgrad_desc& d) {
+    auto width = [](const float* base, int64_t ld, int64_t extent) {
+        auto fits = [&](int v) { return reinterpret_cast<uintptr_t>(base) % (4 * v) == 0 && ld % v == 0 && extent % v == 0; };
+        if (extent > 64 && fits(4)) return 4;
+        if (extent > 32 && fits(2)) return 2;
+        return 1;
+    };
+    WgradShape s{width(d.dY, d.ldy, d.N), width(d.X, d.ldx, d.K), 0};
+    while (s.tn * s.tk > 8) {
+        if (s.tk >= s.tn) s.tk /= 2;
+        else s.tn /= 2;
+    }
+    s.tiles = hmx_ceil_div(d.N, 32 * s.tn) * hmx_ceil_div(d.K, 32 * s.tk);
+    return s;
+}
+static bool wgrad_groups_ok(const hmx_wgrad_desc& d) {
+    auto ok = [](int64_t extent, int32_t g, int32_t gp) {
+        if (g == 0 && gp == 0) return true;
+        return g > 0 && gp >= g && extent % gp == 0;
+    };
+    return ok(d.N, d.n_group, d.n_group_padded) && ok(d.K, d.k_group, d.k_group_padded);
 }
 
 // The counters of a launch: the slot that belongs to the launch's (device, stream).  Launches on one stream run one
@@ -1311,14 +1456,27 @@ static int wgrad_tickets_for_call(hipStream_t stream, unsigned** out) {
     return HMX_OK;
 }
 
-extern "C" size_t hmx_linear_wgrad_batch_workspace_bytes(const hmx_wgrad_desc* descs, int64_t n) {
-    int64_t tiles = 0, t_max = 1;
+// Walks the descriptors of a batch: macro tiles and slab floats (per token-split group) of the whole launch.
+struct WgradPlan {
+    int64_t tiles = 0, slab_floats = 0, t_max = 1;
+};
+static WgradPlan wgrad_plan(const hmx_wgrad_desc* descs, int64_t n) {
+    WgradPlan pl;
     for (int64_t j = 0; j < n; ++j) {
-        tiles += wgrad_tiles(descs[j].N, descs[j].K, descs[j].dbias != nullptr);
-        t_max = std::max<int64_t>(t_max, descs[j].T);
+        if (descs[j].N <= 0 || descs[j].K <= 0) continue;
+        const WgradShape sh = wgrad_shape(descs[j]);
+        pl.tiles += sh.tiles;
+        pl.slab_floats += sh.tiles * wgrad_slab_floats(sh.tn, sh.tk);
+        pl.t_max = std::max<int64_t>(pl.t_max, descs[j].T);
     }
-    if (tiles == 0) return 256;
-    return (size_t)wgrad_groups(t_max, tiles) * tiles * 1024 * sizeof(float) + 256;
+    return pl;
+}
+
+extern "C" size_t hmx_linear_wgrad_batch_workspace_bytes(const hmx_wgrad_desc* descs, int64_t n) {
+    if (!descs || n <= 0) return 256;
+    const WgradPlan pl = wgrad_plan(descs, n);
+    if (pl.tiles == 0) return 256;
+    return (size_t)(wgrad_groups(pl.t_max, pl.tiles) * pl.slab_floats) * sizeof(float) + 256;
 }
 
 extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n, void* workspace, size_t workspace_bytes,
@@ -1327,28 +1485,33 @@ extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n
     if (n == 0) return HMX_OK;
     if (!descs || n < 0 || n > kWgradMaxJobs || !workspace) return HMX_EINVAL;
     if (workspace_bytes < hmx_linear_wgrad_batch_workspace_bytes(descs, n)) return HMX_EWORKSPACE;
+    const WgradPlan pl = wgrad_plan(descs, n);
+    if (pl.tiles > kWgradMaxTiles) return HMX_EINVAL;
+    const int64_t G = wgrad_groups(pl.t_max, std::max<int64_t>(pl.tiles, 1));
     WgradParams p{};
-    int64_t tiles = 0, t_max = 1;
+    int64_t tiles = 0, slab0 = 0;
     int nj = 0;
     for (int64_t j = 0; j < n; ++j) {
         const hmx_wgrad_desc& d = descs[j];
         if (d.N == 0 || d.K == 0) continue;
-        if (!d.dY || !d.X || !d.dW || d.T <= 0 || d.N < 0 || d.K < 0) return HMX_EINVAL;
+        if (!d.dY || !d.X || !d.dW || d.T <= 0 || d.N < 0 || d.K < 0 || !wgrad_groups_ok(d)) return HMX_EINVAL;
+        const WgradShape sh = wgrad_shape(d);
         WgradJob& jb = p.job[nj++];
         jb.dY = d.dY; jb.X = d.X; jb.in_rowmask = d.in_rowmask; jb.dW = d.dW; jb.dbias = d.dbias;
         jb.ldy = d.ldy; jb.ldx = d.ldx; jb.ldw = d.ldw; jb.T = d.T;
         jb.N = (int)d.N; jb.K = (int)d.K; jb.with_bias = d.dbias != nullptr; jb.accumulate = d.accumulate != 0;
+        jb.tn = sh.tn; jb.tk = sh.tk;
+        jb.n_grp = d.n_group; jb.n_grpp = d.n_group_padded; jb.k_grp = d.k_group; jb.k_grpp = d.k_group_padded;
         jb.tile0 = (int)tiles;
-        tiles += wgrad_tiles(d.N, d.K, d.dbias != nullptr);
-        t_max = std::max<int64_t>(t_max, d.T);
+        jb.slab0 = slab0;
+        tiles += sh.tiles;
+        slab0 += G * sh.tiles * wgrad_slab_floats(sh.tn, sh.tk);
     }
     if (nj == 0) return HMX_OK;
-    if (tiles > kWgradMaxTiles) return HMX_EINVAL;
     p.n_jobs = nj;
     p.part = static_cast<float*>(workspace);
     const int rc = wgrad_tickets_for_call((hipStream_t)stream, &p.tickets);
     if (rc != HMX_OK) return rc;
-    const int64_t G = wgrad_groups(t_max, tiles);
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)G, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
     hmx_profile_end(span, (hipStream_t)stream);
@@ -1357,10 +1520,14 @@ extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n
 }
 
 extern "C" size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K) {
-    hmx_wgrad_desc d{};
-    d.T = T; d.N = N; d.K = K;
-    d.dbias = reinterpret_cast<float*>(1);      // size for the variant with a bias column
-    return hmx_linear_wgrad_batch_workspace_bytes(&d, 1);
+    if (T <= 0 || N <= 0 || K <= 0) return 256;
+    int64_t floats = 0;                         // the operands' alignment picks the macro tile: enough for any of them
+    for (int tn = 1; tn <= 4; tn *= 2)
+        for (int tk = 1; tk * tn <= 8 && tk <= 4; tk *= 2) {
+            const int64_t tiles = hmx_ceil_div(N, 32 * tn) * hmx_ceil_div(K, 32 * tk);
+            floats = std::max<int64_t>(floats, wgrad_groups(T, tiles) * tiles * wgrad_slab_floats(tn, tk));
+        }
+    return (size_t)floats * sizeof(float) + 256;
 }
 
 extern "C" int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, const float* in_rowmask,
@@ -1369,7 +1536,7 @@ extern "C" int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X
     if (N == 0 || K == 0) return HMX_OK;
     if (!dY || !X || !dW || !workspace || T <= 0) return HMX_EINVAL;
     if (workspace_bytes < hmx_linear_wgrad_workspace_bytes(T, N, K)) return HMX_EWORKSPACE;
-    hmx_wgrad_desc d{dY, ldy, X, ldx, in_rowmask, T, N, K, dW, ldw, dbias, 0};
+    hmx_wgrad_desc d{dY, ldy, X, ldx, in_rowmask, T, N, K, dW, ldw, dbias, 0, 0, 0, 0, 0};
     return hmx_linear_wgrad_batch_f32(&d, 1, workspace, workspace_bytes, stream);
 }
 

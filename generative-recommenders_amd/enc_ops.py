@@ -195,8 +195,9 @@ class _WgradQueue:
     def __init__(self):
         self.jobs, self.keep, self.targets, self.tiles = [], [], set(), 0
 
-    def add(self, dy, dy_off, ldy, x, x_off, ldx, in_mask, T, N, K, dw, dw_off, ldw, db, db_off):
-        """dW[dw_off ...] += dY^T X (and dbias += column sums of dY); offsets are in elements."""
+    def add(self, dy, dy_off, ldy, x, x_off, ldx, in_mask, T, N, K, dw, dw_off, ldw, db, db_off, groups=(0, 0, 0, 0)):
+        """dW[dw_off ...] += dY^T X (and dbias += column sums of dY); offsets are in elements.  groups: (n_group,
+        n_group_padded, k_group, k_group_padded) of hmx_wgrad_desc -- widened operands against a true weight."""
         tw = dw.data_ptr() + 4 * dw_off
         tb = db.data_ptr() + 4 * db_off if db is not None else None
         tiles = -(-N // 32) * -(-(K + (tb is not None)) // 32)       # 32 x 32 output tiles, bias as one more column
@@ -205,7 +206,7 @@ class _WgradQueue:
             self.flush()
         self.tiles += tiles
         d = hmx.WgradDesc(dy.data_ptr() + 4 * dy_off, ldy, x.data_ptr() + 4 * x_off, ldx,
-                          in_mask.data_ptr() if in_mask is not None else None, T, N, K, tw, ldw, tb, 1)
+                          in_mask.data_ptr() if in_mask is not None else None, T, N, K, tw, ldw, tb, 1, *groups)
         self.jobs.append(d)
         self.keep.append((dy, x, in_mask, dw, db))
         self.targets.add(tw)

@@ -17,7 +17,8 @@ class WgradDesc(ctypes.Structure):
     """hmx_wgrad_desc of include/hmx.h."""
     _fields_ = [("dY", c_void_p), ("ldy", c_int64), ("X", c_void_p), ("ldx", c_int64), ("in_rowmask", c_void_p),
                 ("T", c_int64), ("N", c_int64), ("K", c_int64), ("dW", c_void_p), ("ldw", c_int64),
-                ("dbias", c_void_p), ("accumulate", c_int32)]
+                ("dbias", c_void_p), ("accumulate", c_int32), ("n_group", c_int32), ("n_group_padded", c_int32),
+                ("k_group", c_int32), ("k_group_padded", c_int32)]
 
 
 class AdamwTable(ctypes.Structure):

@@ -296,7 +296,10 @@ int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, in
                    int accumulate, void* stream);
 
 /* Weight / bias gradient on fp32 MFMA: dW[n * ldw + k] = sum_t dY[t, n] * X[t, k] * in_rowmask[t],
- * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  One launch: token splits write partial tiles to the workspace and
+ * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  A wave owns up to eight 32 x 32 output tiles and reads its operands
+ * with vector loads where base, row stride and extent allow (16-byte aligned dY / X with ldy, ldx, N, K multiples of
+ * four give the widest tiles; anything else still works, with more re-reads of the operands).
+ * One launch: token splits write partial tiles to the workspace and
  * the workgroup that finishes a tile last adds them in split order (deterministic, no float atomics).  The arrival
  * counters of that hand-over live inside the library (zero between launches), one set per (GPU, stream): launches on
  * up to sixteen streams of a GPU may be in flight at once (a seventeenth stream takes over the set of the stream
@@ -312,6 +315,11 @@ typedef struct hmx_wgrad_desc {
     int64_t ldw;
     float* dbias;             /* (N) or NULL                                                  */
     int32_t accumulate;       /* 0: dW / dbias are overwritten; 1: the result is added to them */
+    /* Grouped outputs (all four 0: none).  dY's N columns are n_group_padded-wide groups of which the first n_group
+     * are real: column g * n_group_padded + r (r < n_group) is output row g * n_group + r of dW / dbias, the other
+     * columns are skipped; the same along K with the k_ fields.  This is how the widened activations of a fused
+     * block address the true weight: N, K, ldy, ldx describe the widened operands, dW / ldw / dbias the true ones. */
+    int32_t n_group, n_group_padded, k_group, k_group_padded;
 } hmx_wgrad_desc;
 size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K);
 int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, const float* in_rowmask, int64_t T,

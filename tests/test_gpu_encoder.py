@@ -109,6 +109,98 @@ def test_linear_kernel_vs_fp32(T, N, K):
     close(r1d.grad, rr.grad, 1e-6, 1e-6, "dr1")
 
 
+def _wgrad_case(T, N, K, dy_off=0, x_off=0, pad=0, bias=True, mask=True, groups=None, accumulate=True, seed=0):
+    """One descriptor on column-slice views (offsets / row padding in floats) and its float64 answer."""
+    from generative_recommenders_amd import hmx
+    g = torch.Generator().manual_seed(seed + T + 7 * N + 13 * K)
+    dy_full = torch.randn(T, N + dy_off + pad, generator=g)
+    x_full = torch.randn(T, K + x_off + pad, generator=g)
+    m = (torch.rand(T, generator=g) > 0.25).float() if mask else None
+    dy, x = dy_full[:, dy_off:dy_off + N], x_full[:, x_off:x_off + K]
+    ref_w = dy.double().t() @ (x.double() * (m.double()[:, None] if mask else 1.0))
+    ref_b = dy.double().sum(0)
+    if groups:                                         # keep the real columns of every padded group
+        ng, ngp, kg, kgp = groups
+        rows = torch.arange(N)[(torch.arange(N) % ngp) < ng]
+        cols = torch.arange(K)[(torch.arange(K) % kgp) < kg]
+        ref_w, ref_b = ref_w[rows][:, cols], ref_b[rows]
+    w0 = torch.randn(ref_w.shape, generator=g)
+    b0 = torch.randn(ref_b.shape, generator=g)
+    if accumulate:
+        ref_w, ref_b = ref_w + w0.double(), ref_b + b0.double()
+    dev = dict(dy=dy_full.to(DEV), x=x_full.to(DEV), m=m.to(DEV) if mask else None, w=w0.to(DEV).contiguous(),
+               b=b0.to(DEV).contiguous())
+    desc = hmx.WgradDesc(dev["dy"].data_ptr() + 4 * dy_off, dy_full.shape[1], dev["x"].data_ptr() + 4 * x_off,
+                         x_full.shape[1], dev["m"].data_ptr() if mask else None, T, N, K, dev["w"].data_ptr(),
+                         ref_w.shape[1], dev["b"].data_ptr() if bias else None, 1 if accumulate else 0,
+                         *(groups or (0, 0, 0, 0)))
+    return desc, dev, ref_w, (ref_b if bias else b0.double())
+
+
+_WGRAD_CASES = [
+    dict(T=25600, N=64, K=64),                                   # square, 2 x 2 tiles per wave
+    dict(T=4100, N=128, K=128),                                  # 4 x 2
+    dict(T=3000, N=256, K=64, bias=False),                       # 4 x 2, two tiles along N
+    dict(T=3000, N=64, K=256, mask=False),                       # 2 x 4
+    dict(T=777, N=128, K=32, dy_off=128, pad=128),               # 4 x 1 on a column slice
+    dict(T=513, N=32, K=128, x_off=4),                           # 1 x 4, 16-byte aligned slice
+    dict(T=513, N=32, K=128, x_off=2),                           # slice aligned to 8 bytes only: narrower vectors
+    dict(T=900, N=100, K=60),                                    # extents not multiples of 32
+    dict(T=901, N=45, K=33, dy_off=1, x_off=3),                  # nothing aligned: scalar loads
+    dict(T=64, N=64, K=64, groups=(30, 32, 30, 32)),             # widened head groups 30 -> 32
+    dict(T=5000, N=128, K=128, groups=(40, 64, 40, 64), accumulate=False),
+    dict(T=3, N=16, K=8), dict(T=1, N=64, K=64),
+    dict(T=131, N=36, K=128, bias=False, mask=False),
+]
+
+
+@pytest.mark.parametrize("case", _WGRAD_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_weight_gradient_product_vs_float64(case):
+    """hmx_linear_wgrad_batch_f32 on one descriptor: every macro-tile shape, slices of wider rows, grouped outputs,
+    with and without bias / row mask / accumulation.  fp32 MFMA sums in a fixed order: 2e-6 of the product's scale
+    (sqrt(T) times the operand scale) covers the rounding of T-term sums."""
+    from generative_recommenders_amd import hmx
+    desc, dev, ref_w, ref_b = _wgrad_case(**case)
+    lib = hmx.lib()
+    arr = (hmx.WgradDesc * 1)(desc)
+    ws = torch.empty(lib.hmx_linear_wgrad_batch_workspace_bytes(arr, 1), dtype=torch.uint8, device=DEV)
+    for _ in range(2):                                 # twice: the arrival counters must be back at zero
+        w_before, b_before = dev["w"].clone(), dev["b"].clone()
+        hmx.check(lib.hmx_linear_wgrad_batch_f32(arr, 1, ws.data_ptr(), ws.numel(), hmx.current_stream()), "wgrad")
+        torch.cuda.synchronize()
+        tol = 2e-6 * (case["T"] ** 0.5 + 4) * 4
+        assert float((dev["w"].double().cpu() - ref_w).abs().max()) <= tol
+        assert float((dev["b"].double().cpu() - ref_b).abs().max()) <= tol
+        dev["w"].copy_(w_before)
+        dev["b"].copy_(b_before)
+
+
+def test_weight_gradient_batch_of_mixed_shapes():
+    """Several products of different macro-tile shapes in one launch, each against float64."""
+    from generative_recommenders_amd import hmx
+    cases = [c for c in _WGRAD_CASES if c["T"] <= 5000][:9]
+    built = [_wgrad_case(**c, seed=i) for i, c in enumerate(cases)]
+    lib = hmx.lib()
+    arr = (hmx.WgradDesc * len(built))(*[b[0] for b in built])
+    ws = torch.empty(lib.hmx_linear_wgrad_batch_workspace_bytes(arr, len(built)), dtype=torch.uint8, device=DEV)
+    hmx.check(lib.hmx_linear_wgrad_batch_f32(arr, len(built), ws.data_ptr(), ws.numel(), hmx.current_stream()), "wgrad")
+    torch.cuda.synchronize()
+    for c, (_, dev, ref_w, ref_b) in zip(cases, built):
+        tol = 2e-6 * (c["T"] ** 0.5 + 4) * 4
+        assert float((dev["w"].double().cpu() - ref_w).abs().max()) <= tol, c
+        assert float((dev["b"].double().cpu() - ref_b).abs().max()) <= tol, c
+
+
+def test_weight_gradient_rejects_inconsistent_groups():
+    from generative_recommenders_amd import hmx
+    desc, dev, _, _ = _wgrad_case(T=64, N=64, K=64, groups=(30, 32, 30, 32))
+    desc.n_group_padded = 24                           # 64 is not a multiple of 24, and the group is wider than its pad
+    arr = (hmx.WgradDesc * 1)(desc)
+    lib = hmx.lib()
+    ws = torch.empty(lib.hmx_linear_wgrad_batch_workspace_bytes(arr, 1), dtype=torch.uint8, device=DEV)
+    assert lib.hmx_linear_wgrad_batch_f32(arr, 1, ws.data_ptr(), ws.numel(), hmx.current_stream()) != 0
+
+
 def test_selective_scan_kernel_vs_reference_golden():
     """SSM module (deltaBC projection + dt projection + softplus + scan) against the oracle on the same weights."""
     torch.manual_seed(0)
