@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-threshold-exchange", action="store_true",
                     help="N > 1: every item range proves its own top-k (no exchange of sampled thresholds between ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-terms", dest="reference_terms", action="store_true",
+                    help="train workload: also evaluate the negative-item branch and the diversity term that the "
+                         "reference computes and multiplies by its default weights 0.0 (hydra3.py:694-696, 711, 1139-1149)")
     ap.add_argument("--torch-adamw", dest="torch_adamw", action="store_true",
                     help="train workload: torch's clip_grad_norm_ + fused AdamW instead of the HIP optimizer kernels")
     ap.add_argument("--foreach-adamw", dest="foreach_adamw", action="store_true",

@@ -72,6 +72,8 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     B, L, d = args.batch, args.seq_len, args.dim
     model = H.build_model(args.users, args.items, d=d, L=L, dropout=0.2, device=dev, seed=1234)
     model.train()
+    ref_terms = bool(getattr(args, "reference_terms", False))
+    model.enchanced_loss.evaluate_all_terms = ref_terms
     ops_mod.set_fused_table_grad(True)     # table gradients accumulate straight into .grad (same sums, fewer passes)
     from generative_recommenders_amd import enc_ops
     enc_ops.set_direct_param_grad(True)    # weight gradients of the projections: batched launches adding into .grad
@@ -112,7 +114,7 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     for _ in range(max(args.warmup, 1)):
         step()
     TAGS = ("gather_rows", "scatter_segment_sum", "topk_coarse_bf16", "proj", "scan_fwd", "scan_bwd", "nce_fwd", "nce_bwd",
-            "optimizer")
+            "optimizer", "input_assembly")
     # Per-kernel durations of the other tagged kernels: a few extra steps with every bracket on, outside the timed
     # region (each bracket is two event records on the stream; some eighty of them per step are not free).  The timed
     # region itself brackets the roofline kernel (the backward scan) alone.
@@ -145,9 +147,16 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     fwd_bwd_ms = sum(s.elapsed_time(m) for s, m in zip(starts, mids)) / args.steps
     step_s = elapsed / args.steps
 
-    # Row gathers of one step: routed seq gather + pos + 4 small-table lookups (B*L ids each); the hard-negative
-    # gather lives inside the fused loss kernel.  520 B per id at d = 64 (8 B index + row read + row write).
-    n_ids = 6 * B * L
+    # Row gathers of one step: the pos_seqs item rows (B*L ids; 520 B per id at d = 64: 8 B index + row read + row
+    # write).  The sequence's own rows (routed item / user gather, position, time, action, dwell) are read inside the
+    # input-assembly kernel and the hard negatives inside the fused loss kernel.
+    n_ids = B * L
+    # Input assembly, forward launch: per token five 8-byte indices, one ds-float table row (the position and small-table
+    # rows repeat and come from cache), the d-float output and, in training, the ds-float row sum kept for the weight
+    # gradient.  Backward launch: reads dout, writes g, gs (d floats each) and de (ds floats).
+    ds_w = model.shared_embeddings.item_emb.embedding_dim
+    ia_ms, ia_n = spans["input_assembly"]
+    ia_bytes = B * L * ((40 + 4 * (2 * ds_w + d)) + 4 * (3 * d + ds_w))
     g_ms, g_n = spans["gather_rows"]
     c_ms, c_n = spans["topk_coarse_bf16"]
     miner_tf = 2.0 * B * (args.items + 1) * d * args.steps / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
@@ -266,10 +275,14 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                                                           "torch": "torch clip_grad_norm_ + torch.optim.AdamW(fused=True)",
                                                           "foreach": "torch clip_grad_norm_ + torch.optim.AdamW"}[which_opt] +
                                "); table and projection-weight gradients "
-                               "accumulated directly into .grad. Not evaluated: "
-                               "the neg_seqs gather + projection and the diversity term, which the reference computes "
-                               "and multiplies by its default weights 0.0 (hydra3.py:694-696,711,1146-1149): two row "
-                               "gathers per step here (seq, pos), three in the reference",
+                               "accumulated directly into .grad. " +
+                               ("Evaluated like the reference: the neg_seqs gather + projection, the ranking term and the "
+                                "diversity term, multiplied by their default weights 0.0 (hydra3.py:694-696,711,1139-1149) "
+                                "and back-propagated (--reference-terms)" if ref_terms else
+                                "Not evaluated (run with --reference-terms to include them): "
+                                "the neg_seqs gather + projection and the diversity term, which the reference computes "
+                                "and multiplies by its default weights 0.0 (hydra3.py:694-696,711,1146-1149): two row "
+                                "gathers per step here (seq, pos), three in the reference"),
                    "parallelism": f"dp{world}" if world > 1 else "single GPU"},
         "fwd_bwd_ms": fwd_bwd_ms, "fwd_bwd_seqs_per_s": B * world / (fwd_bwd_ms * 1e-3), "loss": float(loss.item()),
         "roofline": {"bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -301,7 +314,6 @@ def run_train(args, world, rank, with_cpu_baseline=True):
                 "launches": p_n, "avg_launch_ms": p_ms / max(p_n, 1), "algorithmic_bytes_per_launch": probe_bytes},
             "gather_rows_bf16_kernel probe (hbm)": {
                 "achieved_GBps_moved": gather_bf16_gbs,
-                "achieved_GBps_at_the_fp32_accounting": probe_bytes * b_n / (b_ms * 1e-3) / 1e9 if b_ms > 0 else 0.0,
                 "avg_launch_ms": b_ms / max(b_n, 1), "bytes_moved_per_launch": probe_bytes_bf16,
                 "note": "same ids; the output row is bf16, so a launch moves 392 B per id at d = 64 instead of 520"},
             "gather_rows_kernel probe, Zipf(1.05) ids (hbm + cache)": {
@@ -310,6 +322,13 @@ def run_train(args, world, rank, with_cpu_baseline=True):
             f"scatter_add_rows probe, {n_probe} rows of d {d} into the dense item gradient (sort + run sums, hbm)": scatter,
             "gather_rows_kernel inside the step": {"ids_per_step": n_ids, "launches": g_n,
                                                    "ms_per_step": g_ms / args.steps},
+            "input_assembly kernels (forward + backward, hbm)": {
+                "ms_per_step": ia_ms / args.steps, "launches": ia_n,
+                "algorithmic_bytes_per_step": ia_bytes,
+                "achieved_GBps": ia_bytes * args.steps / (ia_ms * 1e-3) / 1e9 if ia_ms > 0 else 0.0,
+                "note": "routed item / user row + position row -> hydra_projection on the matrix cores -> + time / action / "
+                        "dwell rows, mask; the gathered rows are not written (training keeps their sum for the weight "
+                        "gradient)"},
             "coarse scoring kernels (miner, mfma)": {"achieved_tflops": miner_tf, "frac_of_2500": miner_tf / 2500.0,
                                                      "ms_per_step": c_ms / args.steps},
             "embedding scatter-add (sort + run sums, hbm)": {"ms_per_step": s_ms / args.steps, "launches": s_n}},

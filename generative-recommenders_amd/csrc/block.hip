@@ -923,6 +923,179 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_pre_bwd_kernel(Block
     dsc.flush(p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
 }
 
+// ------------------------------------------------------------------ input assembly (hydra3.py:621-669)
+// seqs[t] = ((Wh[:, :ds] (table_row(t) + pos_row(t)) + bh + pre[t]) * sqrt(d) + time[tb(t)] + action[a(t)] + dwell[w(t)]) * pm(t)
+// One wave per 32 tokens, tokens on the MFMA columns like the block halves.  The workgroup converts the projection
+// weight to bf16 hi / lo fragments in LDS at its start (16 KB at 64 x 64); a lane then reads ITS token's two table rows
+// k-step by k-step straight into B fragments, so the gathered rows never exist in memory (training keeps their sum
+// for the weight gradient).  Index work of the reference (padding mask, positions, time-interval bins) is done on the way.
+struct AssemblyParams {
+    int64_t T;
+    int L, ds, d, time_span;
+    const int64_t *ids, *token_type, *ts, *action, *dwell;
+    const float *item_table, *user_table, *pos_table;
+    int64_t item_rows, user_rows, pos_rows;
+    const float* W;          // (d, ldw), first ds columns
+    int64_t ldw;
+    const float* bias;       // (d)
+    const float* pre;        // (T, d) or null
+    float scale;
+    const float *time_rows, *action_rows, *dwell_rows;   // (n, d) each
+    int64_t time_n, action_n, dwell_n;
+    float* out;              // (T, d)
+    float* mask;             // (T)
+    int64_t* pos_idx;        // (T)
+    int64_t* time_bin;       // (T)
+    float* e;                // (T, ds) or null: table row + position row
+    // backward
+    const float* dout;       // (T, d)
+    const float* pmask;      // (T)
+    float* g;                // (T, d)   dout * pm
+    float* gs;               // (T, d)   g * scale
+    float* de;               // (T, ds)  Wh[:, :ds]^T gs
+};
+
+// fragments of the (N x K) weight view Wv(n, k) = W[n * rs + k * cs] into w_lds, entry order of block_pack_kernel
+__device__ __forceinline__ void weight_frags_to_lds(const float* W, int64_t rs, int64_t cs, int NTo, int KS) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    for (int idx = wave; idx < NTo * KS; idx += blockDim.x >> 6) {
+        const int nt = idx / KS, ks = idx % KS;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = W[(int64_t)(32 * nt + i) * rs + (int64_t)(16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)) * cs];
+        const Frag f = make_frag(v);
+        w_lds[(size_t)idx * 128 + lane] = __builtin_bit_cast(uint4, f.hi);
+        w_lds[(size_t)idx * 128 + 64 + lane] = __builtin_bit_cast(uint4, f.lo);
+    }
+    __syncthreads();
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void input_assembly_fwd_kernel(AssemblyParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int KS = p.ds / 16, d = 32 * NT;
+    weight_frags_to_lds(p.W, p.ldw, 1, NT, KS);
+    const WSrc<true> src{reinterpret_cast<const uint4*>(p.W), 0u, (unsigned)(NT * KS * 128)};
+    const int64_t n_tiles = hmx_ceil_div(p.T, 32);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t t = tile * 32 + i;
+        const bool ok = t < p.T;
+        const int64_t tt = ok ? t : p.T - 1;
+        // index preparation (hydra3.py:621, 629-635, 650-659)
+        const int l = tile_pos(tile, i, p.L);
+        const int64_t id = p.ids[tt];
+        const bool valid = id != 0;
+        const int64_t pos = valid ? l + 1 : 0;
+        int64_t dt = 0;
+        if (ok && l > 0 && p.ids[tt - 1] != 0) dt = p.ts[tt] - p.ts[tt - 1];
+        int64_t bin = (int64_t)logf((float)dt + 1.0f);
+        bin = bin > p.time_span - 1 ? p.time_span - 1 : bin;
+        const int64_t tb = valid ? bin : 0;
+        const float pm = valid ? 1.f : 0.f;
+        const int64_t typ = p.token_type[tt];
+        const float* row = nullptr;                     // embedding.py:436-450: item rows, user rows, zeros elsewhere
+        if (typ == 1 && id >= 0 && id < p.item_rows) row = p.item_table + id * p.ds;
+        else if (typ == 2 && id >= 0 && id < p.user_rows) row = p.user_table + id * p.ds;
+        const float* prow = pos < p.pos_rows ? p.pos_table + pos * p.ds : nullptr;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) load_tile(acc[nt], p.bias, nt, h);
+        for (int ks0 = 0; ks0 < KS; ks0 += 4) {          // ds is a multiple of 32: two or four k-steps requested together
+            RawFrag ra[4], rb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[u].a = ra[u].b = rb[u].a = rb[u].b = z;
+                if (ks0 + u < KS) {
+                    if (row != nullptr) ra[u] = row_raw(row, ks0 + u, h);
+                    if (prow != nullptr) rb[u] = row_raw(prow, ks0 + u, h);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ks0 + u < KS) {
+                    RawFrag r;
+                    r.a = make_float4(ra[u].a.x + rb[u].a.x, ra[u].a.y + rb[u].a.y, ra[u].a.z + rb[u].a.z, ra[u].a.w + rb[u].a.w);
+                    r.b = make_float4(ra[u].b.x + rb[u].b.x, ra[u].b.y + rb[u].b.y, ra[u].b.z + rb[u].b.z, ra[u].b.w + rb[u].b.w);
+                    if (p.e != nullptr && ok) {
+                        *reinterpret_cast<float4*>(p.e + t * p.ds + 16 * (ks0 + u) + 4 * h) = r.a;
+                        *reinterpret_cast<float4*>(p.e + t * p.ds + 16 * (ks0 + u) + 8 + 4 * h) = r.b;
+                    }
+                    const Frag f = raw_frag(r);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma<true>(acc[nt], src, 0, nt, KS, ks0 + u, f, lane);
+                }
+            }
+        }
+        const int64_t a = p.action[tt], w = p.dwell[tt];
+        const float* trow = tb >= 0 && tb < p.time_n ? p.time_rows + tb * d : nullptr;
+        const float* arow = a >= 0 && a < p.action_n ? p.action_rows + a * d : nullptr;
+        const float* wrow = w >= 0 && w < p.dwell_n ? p.dwell_rows + w * d : nullptr;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 tr, ar, wr, o;
+            zero(tr); zero(ar); zero(wr);
+            if (trow != nullptr) load_tile(tr, trow, nt, h);
+            if (arow != nullptr) load_tile(ar, arow, nt, h);
+            if (wrow != nullptr) load_tile(wr, wrow, nt, h);
+            if (p.pre != nullptr) {
+                f32x16 pr;
+                load_tile(pr, p.pre + tt * d, nt, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] += pr[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = (((acc[nt][r] * p.scale + tr[r]) + ar[r]) + wr[r]) * pm;
+            if (ok) store_tile(o, p.out + t * d, nt, h);
+        }
+        if (ok && h == 0) {
+            p.mask[t] = pm;
+            p.pos_idx[t] = pos;
+            p.time_bin[t] = tb;
+        }
+    }
+}
+
+// g = dout * pm, gs = g * scale, de = Wh[:, :ds]^T gs  (MT = ds / 32 output tiles)
+template <int NT>
+__global__ __launch_bounds__(256) void input_assembly_bwd_kernel(AssemblyParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int d = 32 * NT, MT = p.ds / 32, KS = 2 * NT;
+    weight_frags_to_lds(p.W, 1, p.ldw, MT, KS);          // transposed view: (ds x d)
+    const WSrc<true> src{reinterpret_cast<const uint4*>(p.W), 0u, (unsigned)(MT * KS * 128)};
+    const int64_t n_tiles = hmx_ceil_div(p.T, 32);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t t = tile * 32 + i;
+        const bool ok = t < p.T;
+        const int64_t tt = ok ? t : p.T - 1;
+        const float pm = ok ? p.pmask[tt] : 0.f;
+        Frag gf[2 * NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 g, gs;
+            load_tile(g, p.dout + tt * d, nt, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                g[r] *= pm;
+                gs[r] = g[r] * p.scale;
+            }
+            if (ok) {
+                store_tile(g, p.g + t * d, nt, h);
+                store_tile(gs, p.gs + t * d, nt, h);
+            }
+            tile_frags(gs, gf[2 * nt], gf[2 * nt + 1]);
+        }
+#pragma unroll 1
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x16 acc;
+            zero(acc);
+#pragma unroll
+            for (int ks = 0; ks < 2 * NT; ++ks) mma<true>(acc, src, 0, mt, KS, ks, gf[ks], lane);
+            if (ok) store_tile(acc, p.de + t * p.ds, mt, h);
+        }
+    }
+}
+
 // workgroups of a launch whose workgroups hold `waves` waves (one 32-token tile per wave and trip)
 inline int block_grid(int64_t T, int waves = 4) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(hmx_ceil_div(hmx_ceil_div(T, 32), waves), 8192 / waves));
@@ -1109,6 +1282,102 @@ extern "C" int hmx_block_pre_bwd(const hmx_block_args* a, void* stream) {
         return HMX_EINVAL;
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     HMX_BLOCK_DISPATCH(block_pre_bwd_kernel, true, p, p.lay.w1, p.lay.wint + p.lay.wint_stride * p.lay.H, (hipStream_t)stream);
+    hmx_profile_end(span, (hipStream_t)stream);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static bool assembly_shape_ok(const hmx_input_assembly_args* a) {
+    if (!a || a->T < 0 || a->L <= 0 || a->d <= 0 || a->ds <= 0) return false;
+    if (a->d % 32 || a->d > 32 * kMaxNT || a->ds % 32 || a->ds > 256) return false;
+    if ((size_t)(a->d / 32) * (a->ds / 16) * 128 * sizeof(uint4) > kMaxWeightLds) return false;
+    return a->W != nullptr && a->ldw >= a->ds;
+}
+
+extern "C" int hmx_input_assembly_supported(int64_t d, int64_t ds) {
+    hmx_input_assembly_args a{};
+    a.T = 1; a.L = 1; a.d = d; a.ds = ds; a.ldw = ds;
+    a.W = reinterpret_cast<const float*>(16);
+    return assembly_shape_ok(&a) ? 1 : 0;
+}
+
+static void fill_assembly(AssemblyParams& p, const hmx_input_assembly_args* a) {
+    p = AssemblyParams{};
+    p.T = a->T; p.L = (int)a->L; p.ds = (int)a->ds; p.d = (int)a->d; p.time_span = (int)a->time_span;
+    p.ids = a->ids; p.token_type = a->token_type; p.ts = a->timestamps; p.action = a->action; p.dwell = a->dwell;
+    p.item_table = a->item_table; p.user_table = a->user_table; p.pos_table = a->pos_table;
+    p.item_rows = a->item_rows; p.user_rows = a->user_rows; p.pos_rows = a->pos_rows;
+    p.W = a->W; p.ldw = a->ldw; p.bias = a->bias; p.pre = a->pre; p.scale = a->scale;
+    p.time_rows = a->time_rows; p.action_rows = a->action_rows; p.dwell_rows = a->dwell_rows;
+    p.time_n = a->time_n; p.action_n = a->action_n; p.dwell_n = a->dwell_n;
+    p.out = a->out; p.mask = a->mask; p.pos_idx = a->pos_idx; p.time_bin = a->time_bin; p.e = a->e;
+    p.dout = a->dout; p.pmask = a->mask; p.g = a->g; p.gs = a->gs; p.de = a->de;
+}
+
+#define HMX_ASSEMBLY_LAUNCH(KERNEL, p, lds, stream)                                                                  \
+    do {                                                                                                             \
+        const dim3 grid(std::min(block_grid((p).T, 4), 1024));                                                       \
+        switch ((p).d / 32) {                                                                                        \
+            case 1:                                                                                                  \
+                hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&KERNEL<1>), (int)kMaxWeightLds);                \
+                hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), lds, stream, p);                                    \
+                break;                                                                                               \
+            case 2:                                                                                                  \
+                hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&KERNEL<2>), (int)kMaxWeightLds);                \
+                hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), lds, stream, p);                                    \
+                break;                                                                                               \
+            case 3:                                                                                                  \
+                hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&KERNEL<3>), (int)kMaxWeightLds);                \
+                hipLaunchKernelGGL((KERNEL<3>), grid, dim3(256), lds, stream, p);                                    \
+                break;                                                                                               \
+            default:                                                                                                 \
+                hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&KERNEL<4>), (int)kMaxWeightLds);                \
+                hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), lds, stream, p);                                    \
+                break;                                                                                               \
+        }                                                                                                            \
+    } while (0)
+
+extern "C" int hmx_input_assembly_fwd(const hmx_input_assembly_args* a, void* stream) {
+    HMX_ENTER();
+    if (!assembly_shape_ok(a)) return HMX_EINVAL;
+    if (a->T == 0) return HMX_OK;
+    if (!a->ids || !a->token_type || !a->timestamps || !a->action || !a->dwell || !a->item_table || !a->user_table ||
+        !a->pos_table || !a->bias || !a->time_rows || !a->action_rows || !a->dwell_rows || !a->out || !a->mask || !a->pos_idx ||
+        !a->time_bin)
+        return HMX_EINVAL;
+    if (a->item_rows <= 0 || a->user_rows <= 0 || a->pos_rows < a->L + 1 || a->time_n <= 0 || a->action_n <= 0 ||
+        a->dwell_n <= 0 || a->time_span <= 0)
+        return HMX_EINVAL;
+    const uintptr_t align = reinterpret_cast<uintptr_t>(a->item_table) | reinterpret_cast<uintptr_t>(a->user_table) |
+                            reinterpret_cast<uintptr_t>(a->pos_table) | reinterpret_cast<uintptr_t>(a->bias) |
+                            reinterpret_cast<uintptr_t>(a->time_rows) | reinterpret_cast<uintptr_t>(a->action_rows) |
+                            reinterpret_cast<uintptr_t>(a->dwell_rows) | reinterpret_cast<uintptr_t>(a->out) |
+                            reinterpret_cast<uintptr_t>(a->pre) | reinterpret_cast<uintptr_t>(a->e);
+    if (align % 16) return HMX_EINVAL;
+    AssemblyParams p;
+    fill_assembly(p, a);
+    const size_t lds = (size_t)(a->d / 32) * (a->ds / 16) * 128 * sizeof(uint4);
+    void* span = hmx_profile_begin("input_assembly", (hipStream_t)stream);
+    HMX_ASSEMBLY_LAUNCH(input_assembly_fwd_kernel, p, lds, (hipStream_t)stream);
+    hmx_profile_end(span, (hipStream_t)stream);
+    HMX_CHECK_LAUNCH();
+    return HMX_OK;
+}
+
+extern "C" int hmx_input_assembly_bwd(const hmx_input_assembly_args* a, void* stream) {
+    HMX_ENTER();
+    if (!assembly_shape_ok(a)) return HMX_EINVAL;
+    if (a->T == 0) return HMX_OK;
+    if (!a->dout || !a->mask || !a->g || !a->gs || !a->de) return HMX_EINVAL;
+    const uintptr_t align = reinterpret_cast<uintptr_t>(a->dout) | reinterpret_cast<uintptr_t>(a->g) |
+                            reinterpret_cast<uintptr_t>(a->gs) | reinterpret_cast<uintptr_t>(a->de);
+    if (align % 16) return HMX_EINVAL;
+    AssemblyParams p;
+    fill_assembly(p, a);
+    const size_t lds = (size_t)(a->ds / 32) * (a->d / 16) * 128 * sizeof(uint4);
+    void* span = hmx_profile_begin("input_assembly", (hipStream_t)stream);
+    HMX_ASSEMBLY_LAUNCH(input_assembly_bwd_kernel, p, lds, (hipStream_t)stream);
     hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;

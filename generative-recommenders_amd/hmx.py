@@ -36,6 +36,18 @@ class BlockWeights(ctypes.Structure):
 _BLOCK_PTRS_IN = ("mask", "x", "drop", "scale1", "b1", "rope_cos", "rope_sin")
 
 
+class InputAssemblyArgs(ctypes.Structure):
+    """hmx_input_assembly_args of include/hmx.h."""
+    _fields_ = ([(k, c_int64) for k in ("T", "L", "ds", "d", "time_span")] +
+                [(k, c_void_p) for k in ("ids", "token_type", "timestamps", "action", "dwell", "item_table", "user_table",
+                                         "pos_table")] +
+                [(k, c_int64) for k in ("item_rows", "user_rows", "pos_rows")] +
+                [("W", c_void_p), ("ldw", c_int64), ("bias", c_void_p), ("pre", c_void_p), ("scale", c_float)] +
+                [(k, c_void_p) for k in ("time_rows", "action_rows", "dwell_rows")] +
+                [(k, c_int64) for k in ("time_n", "action_n", "dwell_n")] +
+                [(k, c_void_p) for k in ("out", "mask", "pos_idx", "time_bin", "e", "dout", "g", "gs", "de")])
+
+
 class BlockArgs(ctypes.Structure):
     """hmx_block_args of include/hmx.h."""
     _fields_ = ([("T", c_int64), ("L", c_int64), ("d", c_int64), ("H", c_int64), ("first", c_int32), ("eps", c_float),
@@ -117,6 +129,9 @@ PROTOTYPES = {
     "hmx_block_scale_partial_rows": (I64, [I64]),
     "hmx_block_padded_width": (I64, [I64, I64]),
     "hmx_block_pack_f32": (c_int, [ctypes.POINTER(BlockWeights), I64, I64, I64, P, P]),
+    "hmx_input_assembly_supported": (c_int, [I64, I64]),
+    "hmx_input_assembly_fwd": (c_int, [ctypes.POINTER(InputAssemblyArgs), P]),
+    "hmx_input_assembly_bwd": (c_int, [ctypes.POINTER(InputAssemblyArgs), P]),
     "hmx_block_pre_fwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
     "hmx_block_post_fwd": (c_int, [ctypes.POINTER(BlockArgs), P]),
     "hmx_block_post_bwd": (c_int, [ctypes.POINTER(BlockArgs), P]),

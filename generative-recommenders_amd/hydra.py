@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import assembly_ops
 from . import block_ops
 from . import enc_ops as E
 from . import feature_ops
@@ -19,6 +20,7 @@ from .enc_ops import pscan, selective_scan   # noqa: F401  (hydra3.py:104, 107: 
 from .shared_embedding import SharedEmbeddingConfig, SharedEmbeddingModule
 
 D_STATE, DT_RANK, D_CONV = 16, 16, 4
+FUSED_INPUT_ASSEMBLY = True     # log2feats builds its input with hmx_input_assembly_fwd where the widths allow
 VALIDATE_HARD_GROUPS = False   # debug switch: verify on the device that broadcast hard-negative lists repeat per sequence
 FUSED_BLOCKS = True      # HydraBlock(First) on the fused block kernels where block_ops.Layout.of(d, heads) exists (d <= 128 after widening)
 
@@ -468,6 +470,10 @@ class EnhancedTrainingLoss(nn.Module):
         self.contrastive_loss_weight = getattr(args, 'contrastive_loss_weight', 1.0)
         self.diversity_loss_weight = getattr(args, 'diversity_loss_weight', 0.0)
         self.q_chunk = getattr(args, 'loss_q_chunk', 256)          # hydra3.py:1132
+        # The reference evaluates the ranking and diversity terms whatever their weights (hydra3.py:1139-1149), i.e.
+        # with the default weights 0.0 it computes them, multiplies by zero and back-propagates zeros.  False: terms
+        # with weight 0.0 are skipped (same loss, same gradients); True: they are evaluated like the reference does.
+        self.evaluate_all_terms = bool(getattr(args, 'evaluate_zero_weight_terms', False))
         self.adaptive_hard_sampler = AdaptiveHardNegativeSampler()
 
     def forward(self, user_embs, pos_embs, neg_embs, hard_negatives, loss_mask, item_table, predrawn=None,
@@ -476,10 +482,10 @@ class EnhancedTrainingLoss(nn.Module):
             user_embs, pos_embs, loss_mask, item_table, hard_negatives, hard_ratio=0.3, T=512, temperature=0.05,
             q_chunk=self.q_chunk, predrawn=predrawn, loss_rows=loss_rows)
         self.adaptive_hard_sampler.update_step()
-        if neg_embs is not None and self.ranking_loss_weight != 0.0:
+        if neg_embs is not None and (self.ranking_loss_weight != 0.0 or self.evaluate_all_terms):
             total = total + self.ranking_loss_weight * self.compute_ranking_loss(
                 user_embs[:, -1], pos_embs[:, -1], neg_embs[:, -1], loss_mask[:, -1].to(user_embs.device))
-        if self.diversity_loss_weight != 0.0:
+        if self.diversity_loss_weight != 0.0 or self.evaluate_all_terms:
             total = total + self.diversity_loss_weight * self.compute_diversity_loss(user_embs[:, -1], item_table)
         return total
 
@@ -545,10 +551,34 @@ class Hydra(nn.Module):
                          col_off=base.shape[-1])
         return y
 
+    def _small_rows(self, table):
+        """A small table as the fused assembly reads it: after embedding_projection.  The padding row keeps its place
+        but is cut out of the graph, as nn.Embedding(padding_idx=0) keeps its gradient at zero."""
+        if isinstance(self.embedding_projection, nn.Identity):
+            return table.weight
+        w = table.weight
+        w = torch.cat([w[:1].detach(), w[1:]], dim=0)
+        return E.linear(w, self.embedding_projection.weight, self.embedding_projection.bias)
+
     def assemble_inputs(self, log_seqs, mask, seq_timestamp, action_type, dwell_bins, seq_feature=None):
         se = self.shared_embeddings
         B, L = log_seqs.shape
         T = B * L
+        d, ds = self.args.hydra_hidden_units, se.item_emb.embedding_dim
+        if (FUSED_INPUT_ASSEMBLY and log_seqs.is_cuda and assembly_ops.supported(d, ds)
+                and L + 1 <= se.pos_emb.num_embeddings):
+            feats = seq_feature if seq_feature is not None else []
+            pre = None
+            if se.has_features and not se._is_empty(feats):
+                feat = se.get_feature_embeddings(feats, True, 'early')
+                pre = E.linear(feat.reshape(-1, feat.shape[-1]), self.hydra_projection.weight, None, col_off=ds)
+            identity = isinstance(self.embedding_projection, nn.Identity)
+            seqs, pm, _, _ = assembly_ops.input_assembly(
+                se.item_emb.weight, se.user_emb.weight, se.pos_emb.weight, self.hydra_projection.weight,
+                self.hydra_projection.bias, pre, self._small_rows(se.time_span_emb), self._small_rows(se.action_emb),
+                self._small_rows(se.dwell_time_emb), log_seqs, mask, seq_timestamp, action_type, dwell_bins,
+                getattr(self.args, 'time_span', 512), d ** 0.5, small_padding_idx=0 if identity else -1)
+            return seqs, pm
         pm, pos, tb = E.seq_index(log_seqs, seq_timestamp, getattr(self.args, 'time_span', 512))
         e, feat = se.embedding_parts(log_seqs.reshape(T), seq_feature if seq_feature is not None else [], mask.reshape(T),
                                      include_user=True, fusion_style='early', pos_seq=pos)
@@ -625,7 +655,8 @@ class Hydra(nn.Module):
                 neg_feature, timestamp, action_type, dwell_bins, predrawn=None):
         """hydra3.py:683-720.  The negative-item branch (gather + projection of neg_seqs, hydra3.py:694-696, 711) and
         the diversity term (:1146-1149) enter the reference's loss with weight 0.0 by default; they are evaluated
-        here only when their weights are non-zero (the loss value and every gradient are the same either way).
+        here only when their weights are non-zero (the loss value and every gradient are the same either way) or when
+        enchanced_loss.evaluate_all_terms asks for the reference's exact sequence of operations.
         predrawn: see compute_mixed_contrastive_loss.  The mined hard-negative ids of the call are kept in
         self.last_mined_ids."""
         E.discard_stale_wgrads()
@@ -639,7 +670,7 @@ class Hydra(nn.Module):
         pos_embs = self._project_ids(*se.embedding_parts(pos_seqs.reshape(B * L), pos_feature, None, False,
                                                          'early')).view(B, L, -1)
         neg_embs = None
-        if self.enchanced_loss.ranking_loss_weight != 0.0:
+        if self.enchanced_loss.ranking_loss_weight != 0.0 or self.enchanced_loss.evaluate_all_terms:
             neg_embs = self._project_ids(*se.embedding_parts(neg_seqs.reshape(B * L), neg_feature, None, False,
                                                              'early')).view(B, L, -1)
         loss_rows.get()      # host-side work, done while the device still has the encoder queued

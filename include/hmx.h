@@ -400,6 +400,46 @@ int hmx_scan_bwd(const float* xc, const float* z, const float* dbc, const float*
                  int64_t ED, int64_t H, float* dxc, float* dz, float* ddbc_part, float* par_part, void* stream);
 int hmx_sum_groups_f32(const float* part, int64_t rows, int64_t groups, int64_t width, float* out, void* stream);
 
+/* -------------------------------------------------------------------------------
+ * Input assembly of the sequence encoder in one pass (hydra3.py:621-669 with embedding.py:436-450, 613-652 for the
+ * ids-plus-positions half of the early-fusion embedding):
+ *   pm[t]  = ids[t] != 0;  pos[t] = pm ? (t mod L) + 1 : 0;  time_bin[t] per hydra3.py:650-659
+ *   e[t]   = (token_type 1: item_table[ids[t]], 2: user_table[ids[t]], else 0) + pos_table[pos[t]]
+ *   out[t] = ((W[:, :ds] e[t] + bias + pre[t]) * scale + time_rows[time_bin[t]] + action_rows[action[t]]
+ *             + dwell_rows[dwell[t]]) * pm[t]
+ * W is hydra_projection's (d, ldw) weight whose first ds columns meet the id embedding; `pre` (T, d) or NULL carries
+ * what the other columns contribute (the feature half, zero in an ids-only batch); time / action / dwell rows are the
+ * three small tables after embedding_projection (the tables themselves when that is the identity).  The projection runs
+ * on bf16 MFMA with split operands (fp32-class, like hmx_linear_f32); gathered rows are never written unless `e` is
+ * given (training: the X operand of the weight gradient).  Out-of-range action / dwell / time ids read as zero rows.
+ * Backward: g = dout * pm, gs = g * scale, de = W[:, :ds]^T gs; the caller scatter-adds de into the item / user /
+ * position tables and g into the small tables (hmx_scatter_add_rows_f32) and queues (gs, e) for the weight gradient.
+ * Shapes: d and ds multiples of 32, d <= 128, ds <= 256 (hmx_input_assembly_supported); pos_rows >= L + 1; tables,
+ * rows and outputs 16-byte aligned. */
+typedef struct hmx_input_assembly_args {
+    int64_t T, L, ds, d, time_span;
+    const int64_t *ids, *token_type, *timestamps, *action, *dwell;      /* (T) each                          */
+    const float *item_table, *user_table, *pos_table;                   /* (rows, ds)                        */
+    int64_t item_rows, user_rows, pos_rows;
+    const float* W;                                                     /* (d, ldw)                          */
+    int64_t ldw;
+    const float* bias;                                                  /* (d)                               */
+    const float* pre;                                                   /* (T, d) or NULL                    */
+    float scale;
+    const float *time_rows, *action_rows, *dwell_rows;                  /* (n, d) each                       */
+    int64_t time_n, action_n, dwell_n;
+    float* out;                                                         /* (T, d)                            */
+    float* mask;                                                        /* (T): pm, written by fwd, read by bwd */
+    int64_t *pos_idx, *time_bin;                                        /* (T) each, written by fwd          */
+    float* e;                                                           /* (T, ds) or NULL, written by fwd   */
+    const float* dout;                                                  /* backward: (T, d)                  */
+    float *g, *gs;                                                      /* backward: (T, d) each             */
+    float* de;                                                          /* backward: (T, ds)                 */
+} hmx_input_assembly_args;
+int hmx_input_assembly_supported(int64_t d, int64_t ds);
+int hmx_input_assembly_fwd(const hmx_input_assembly_args* a, void* stream);
+int hmx_input_assembly_bwd(const hmx_input_assembly_args* a, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Fused halves of a Hydra block (HydraBlockFirst / HydraBlock, hydra3.py:392-457, with MultiHeadMamba :359-389).
  * Everything of a block that has no dependence between tokens runs in two kernels per direction:
