@@ -181,7 +181,7 @@ def run_retrieval(args, world, rank):
                    "queries": args.queries, "items": n_rows, "d": d, "k": k,
                    "parallelism": ((f"{S} item-range shards (one per GPU)" if G == 1 else
                                     f"{S} item-range shards x {G} query groups") +
-                                   f", {os.environ.get('HMX_BENCH_BACKEND', 'nccl')} all_gather + merge"
+                                   f", {os.environ.get('HMX_BENCH_BACKEND', 'nccl')} all_to_all of each rank's query-slice lists + merge + all_gather of the merged results"
                                    if world > 1 else "single GPU"),
                    "item_shards": S, "query_groups": G, "threshold_exchange": retr.seeded is not None},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

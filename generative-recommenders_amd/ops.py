@@ -451,6 +451,32 @@ def touched_rows(x):
     return flags.nonzero().flatten()
 
 
+def touched_flags(x):
+    """One byte per row of x (n_rows, d), non-zero where the row holds (or, for a row-flagged table gradient, was
+    written with) a value: touched_rows without the compaction, hence without a host sync."""
+    _need_cuda(x)
+    x = _f32c(x)
+    st = _FLAGS_BY_PTR.get(x.data_ptr())
+    if st is not None and st.buf.shape == x.shape and not st.dense:
+        return st.flags
+    flags = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+    hmx.check(hmx.lib().hmx_row_any_nonzero_f32(hmx.ptr(x), x.shape[0], x.shape[1], hmx.ptr(flags),
+                                                hmx.current_stream()), "hmx_row_any_nonzero_f32")
+    return flags
+
+
+@torch.no_grad()
+def gather_rows_padded(weight, ids):
+    """weight[ids] with zero rows where ids is negative or past the table (padded id lists); no gradient."""
+    _need_cuda(weight, ids)
+    w = _f32c(weight.detach())
+    idc = _i64c(ids)
+    out = torch.empty(*idc.shape, w.shape[1], dtype=torch.float32, device=w.device)
+    hmx.check(hmx.lib().hmx_gather_rows_f32(hmx.ptr(w), w.shape[0], w.shape[1], hmx.ptr(idc), idc.numel(),
+                                            hmx.ptr(out), hmx.current_stream()), "hmx_gather_rows_f32")
+    return out
+
+
 def sample_thresholds(queries, prepared, k, n_ranges=1, n_values=1):
     """(n_q,) start thresholds the bf16 pass samples from this table (-inf for launch shapes that do not sample):
     at least k sampled rows of the table score that much.  Exchanged between item-range shards (retrieval.py);

@@ -68,15 +68,16 @@ def _all_reduce_sum(t, group, async_op=False):
 
 def _hip_row_ops():
     from . import ops
-    return (lambda table, ids: ops.gather_rows(table, ids),
+    return (ops.gather_rows_padded,
             lambda rows, ids, out: ops.scatter_add_rows(rows, ids, out.shape[0], out=out),
-            ops.touched_rows)
+            ops.touched_rows, ops.touched_flags)
 
 
 class GradientSync:
-    """row_ops = (gather(table, ids) -> rows, scatter_add(rows, ids, out) adding rows into out, ids < 0 ignored
-    [, touched(grad) -> ascending ids of the non-zero rows]): the HIP kernels by default; injectable so that the
-    exchange logic can be exercised on CPU tensors with gloo."""
+    """row_ops = (gather(table, ids) -> rows (zero rows for ids < 0), scatter_add(rows, ids, out) adding rows into out,
+    ids < 0 ignored [, touched(grad) -> ascending ids of the non-zero rows [, touched_flags(grad) -> one byte per row,
+    non-zero where the row was written, computed without a host sync]]): the HIP kernels by default; injectable so that
+    the exchange logic can be exercised on CPU tensors with gloo."""
 
     def __init__(self, params, group=None, big_bytes: int = 32 << 20, average: bool = True,
                  sparse_tables: bool = True, row_ops=None):
@@ -126,7 +127,7 @@ class GradientSync:
                 st = ops.table_grad_state(p)
                 if st is not None:
                     st.mark_dense()
-        pending_sparse = [self._sparse_begin(p, scale) for p in sparse]
+        pending_sparse = self._sparse_begin(sparse, scale)
         flat = self._bucket()
         if flat is not None:
             for p in self.small:
@@ -154,38 +155,60 @@ class GradientSync:
                                "pass row_ops to exercise it elsewhere")
         return _hip_row_ops()
 
-    def _sparse_begin(self, p, scale=1.0):
-        g = p.grad
-        row_ops = self._ops(g)
-        gather = row_ops[0]
-        # rows this rank touched (host sync: their count); torch's form took 1.2 ms on the 4 M x 64 item gradient
-        ids = row_ops[2](g) if len(row_ops) > 2 else (g != 0).any(dim=1).nonzero().flatten()
-        counts = torch.tensor([ids.numel()], dtype=torch.int64, device=g.device)
-        all_counts = torch.empty(self.world, dtype=torch.int64, device=g.device)
+    def _sparse_begin(self, tables, scale=1.0):
+        """Starts the row exchange of every table gradient in `tables`.  The touched-row counts of ALL tables travel in
+        one collective and reach the host in one copy (the step's only host sync here): with row flags at hand
+        (touched_flags) nothing before that copy waits for the device, and the padded id lists are then cut from the
+        flags at exactly the largest count over ranks."""
+        if not tables:
+            return []
+        prep, cnts = [], []
+        for p in tables:
+            g = p.grad
+            row_ops = self._ops(g)
+            if len(row_ops) > 3:
+                flags = row_ops[3](g)
+                prep.append((p, None, flags))
+                cnts.append((flags != 0).sum(dtype=torch.int64).reshape(1))
+            else:
+                ids = row_ops[2](g) if len(row_ops) > 2 else (g != 0).any(dim=1).nonzero().flatten()
+                prep.append((p, ids, None))
+                cnts.append(torch.tensor([ids.numel()], dtype=torch.int64, device=g.device))
+        dev = tables[0].grad.device
+        counts = torch.cat([c.to(dev) for c in cnts])
+        all_counts = torch.empty(self.world * len(tables), dtype=torch.int64, device=dev)
         _all_gather_flat(all_counts, counts, self.group)
-        n_max = int(all_counts.max().item())
-        pad_ids = torch.full((max(n_max, 1),), -1, dtype=torch.int64, device=g.device)
-        pad_rows = torch.zeros(max(n_max, 1), g.shape[1], dtype=g.dtype, device=g.device)
-        if ids.numel():
-            pad_ids[:ids.numel()] = ids
-            pad_rows[:ids.numel()] = gather(g, ids)
+        both = torch.stack([all_counts.view(self.world, len(tables)).max(dim=0).values, counts]).tolist()
+        states = []
+        for (p, ids, flags), n_max, n_own in zip(prep, both[0], both[1]):
+            g = p.grad
+            gather = self._ops(g)[0]
+            n_pad = max(int(n_max), 1)
+            if flags is not None:
+                pad_ids = torch.nonzero_static(flags, size=n_pad, fill_value=-1).flatten()     # ascending, -1 after the last
+            else:
+                pad_ids = torch.full((n_pad,), -1, dtype=torch.int64, device=g.device)
+                pad_ids[:ids.numel()] = ids
+            pad_rows = gather(g, pad_ids)                # ids < 0 give zero rows
             if scale != 1.0:
-                pad_rows.mul_(scale)             # each rank scales what it sends: 1 / world of the gathered volume
-        out_ids = torch.empty(self.world * pad_ids.numel(), dtype=torch.int64, device=g.device)
-        out_rows = torch.empty(self.world * pad_rows.shape[0], g.shape[1], dtype=g.dtype, device=g.device)
-        w1 = _all_gather_flat(out_ids, pad_ids, self.group, async_op=True)
-        w2 = _all_gather_flat(out_rows, pad_rows, self.group, async_op=True)
-        self.last_stats[id(p)] = {"rows_sent": int(ids.numel()), "rows_padded": int(pad_ids.numel())}
-        return p, ids, out_ids, out_rows, (w1, w2)
+                pad_rows.mul_(scale)                     # each rank scales what it sends: 1 / world of the gathered volume
+            out_ids = torch.empty(self.world * n_pad, dtype=torch.int64, device=g.device)
+            out_rows = torch.empty(self.world * n_pad, g.shape[1], dtype=g.dtype, device=g.device)
+            w1 = _all_gather_flat(out_ids, pad_ids, self.group, async_op=True)
+            w2 = _all_gather_flat(out_rows, pad_rows, self.group, async_op=True)
+            self.last_stats[id(p)] = {"rows_sent": int(n_own), "rows_padded": n_pad}
+            states.append((p, pad_ids, out_ids, out_rows, (w1, w2)))
+        return states
 
     def _sparse_finish(self, state):
-        p, ids, out_ids, out_rows, works = state
+        p, pad_ids, out_ids, out_rows, works = state
         for w in works:
             w.wait()
         g = p.grad
         scatter_add = self._ops(g)[1]
-        if ids.numel():
-            g[ids] = 0                                   # this rank's rows come back inside the gathered set
+        # This rank's rows come back inside the gathered set: zero them first.  The -1 padding is pointed at row 0, which
+        # is either one of this rank's rows or was never written here (zero already), so no list has to be compacted.
+        g.index_fill_(0, pad_ids.clamp_min(0), 0.0)
         scatter_add(out_rows, out_ids, g)                # every rank adds all rows in rank order: same bits everywhere
 
     def bytes_per_step(self) -> int:

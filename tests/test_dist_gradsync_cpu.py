@@ -22,12 +22,13 @@ class _Toy(torch.nn.Module):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
         self.table = torch.nn.Parameter(torch.randn(500, 8, generator=g))   # "big": reduced in place
+        self.table2 = torch.nn.Parameter(torch.randn(600, 8, generator=g))  # a second one: both share the count exchange
         self.w = torch.nn.Parameter(torch.randn(8, 8, generator=g))
         self.b = torch.nn.Parameter(torch.randn(8, generator=g))
         self.unused_on_rank1 = torch.nn.Parameter(torch.randn(3, generator=g))
 
     def forward(self, ids, use_extra):
-        h = self.table[ids] @ self.w + self.b
+        h = (self.table[ids] + self.table2[ids // 2 + 7]) @ self.w + self.b
         loss = (h * h).mean()
         if use_extra:
             loss = loss + self.unused_on_rank1.sum() * 0.5
@@ -39,15 +40,21 @@ def _data():
     return torch.randint(0, 500, (64,), generator=g)
 
 
-def _torch_row_ops():
-    """CPU stand-ins for the HIP gather / scatter-add (same contract: ids < 0 are ignored)."""
+def _torch_row_ops(with_flags=False):
+    """CPU stand-ins for the HIP gather / scatter-add (same contract: ids < 0 give zero rows / are ignored)."""
     def gather(table, ids):
-        return table[ids]
+        return table[ids.clamp_min(0)] * (ids >= 0).unsqueeze(1)
 
     def scatter_add(rows, ids, out):
         keep = ids >= 0
         out.index_add_(0, ids[keep], rows[keep])
-    return gather, scatter_add
+
+    def touched(g):
+        return (g != 0).any(dim=1).nonzero().flatten()
+
+    def touched_flags(g):
+        return (g != 0).any(dim=1).to(torch.uint8)
+    return (gather, scatter_add, touched, touched_flags) if with_flags else (gather, scatter_add)
 
 
 def _worker(rank, world, port, out_dir, sparse=False):
@@ -55,8 +62,9 @@ def _worker(rank, world, port, out_dir, sparse=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model = _Toy(seed=100 + rank)           # different init per rank: broadcast must fix that
     broadcast_parameters(model, src=0)
-    sync = GradientSync(model, big_bytes=500 * 8 * 4, sparse_tables=sparse, row_ops=_torch_row_ops() if sparse else None)
-    assert [tuple(p.shape) for p in sync.big] == [(500, 8)] and len(sync.small) == 3
+    sync = GradientSync(model, big_bytes=500 * 8 * 4, sparse_tables=bool(sparse),
+                        row_ops=_torch_row_ops(with_flags=sparse == "flags") if sparse else None)
+    assert [tuple(p.shape) for p in sync.big] == [(500, 8), (600, 8)] and len(sync.small) == 3
     ids = _data()[rank * 32:(rank + 1) * 32]
     for _ in range(2):                      # second pass reuses the flat bucket
         model.zero_grad(set_to_none=True)
@@ -69,7 +77,7 @@ def _worker(rank, world, port, out_dir, sparse=False):
 import pytest
 
 
-@pytest.mark.parametrize("sparse", [False, True])
+@pytest.mark.parametrize("sparse", [False, True, "flags"])
 def test_two_rank_gradients_equal_whole_batch(tmp_path, sparse):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), sparse), nprocs=2, join=True)
     ref = _Toy(seed=100)

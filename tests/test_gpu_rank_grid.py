@@ -1,5 +1,5 @@
 """ShardedRetriever's own search code for whole rank grids (up to eight ranges) on ONE GPU in ONE process: every rank is
-a thread, the all_gather is a hand-over between the threads, and only one thread runs at a time (the library's
+a thread, the collectives are hand-overs between the threads, and only one thread runs at a time (the library's
 workspace is shared).  Odd shapes: ranges shorter than k, empty trailing ranges, ragged last query group, one query,
 k = 1 and k = 16, d = 128.  The result must equal the unsharded kernel's (itself pinned to the C oracle), and the
 oracle's on a slice.  GradientSync's exchange runs the same way for 4 and 8 ranks."""
@@ -35,6 +35,19 @@ class _Grid:
         self._meet()                            # nobody overwrites a slot before all have read it
         return out, ShardedRetriever._Done()
 
+    def exchange(self, rank, send, S):
+        """all_to_all within a query group: block j of the result is what the group's j-th rank sent in its block
+        number (rank % S)."""
+        self.slots[rank] = send
+        self.calls[rank] += 1
+        self._meet()
+        assert len(set(self.calls)) == 1, "ranks disagree on the number of collectives"
+        assert len({(tuple(s.shape), s.dtype) for s in self.slots}) == 1, "ranks disagree on a collective's shape"
+        g, me = rank // S, rank % S
+        out = torch.stack([self.slots[g * S + j][me] for j in range(S)])
+        self._meet()
+        return out, ShardedRetriever._Done()
+
     def _meet(self):
         self.turn.release()
         try:
@@ -58,6 +71,7 @@ def _run_grid(table, queries, k, world, item_shards, chunk, exchange=True):
             if exchange and S > 1:
                 r.seeded = (r._hip_sample, r._hip_seeded, r._hip_exact)
             r._all_gather = lambda t, rank=rank: grid.gather(rank, t)
+            r._group_exchange = lambda t, rank=rank, S=S: grid.exchange(rank, t, S)
             ids, sc = r.search(queries, k)
             results[rank] = (ids, sc, dict(r.last_stats))
         except BaseException as e:                               # noqa: BLE001 - reported by the main thread
