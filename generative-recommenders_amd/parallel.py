@@ -19,6 +19,7 @@ messages beat many small ones):
 All collectives are launched asynchronously back to back and waited for together.  A parameter whose
 gradient is None on this rank takes part as zeros, so ranks never disagree about the message sizes.
 """
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -37,6 +38,10 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
                 dist.broadcast(t.data, src=src, group=group)
 
 
+# Diagnostics only: hand gloo the GPU tensors themselves (the form that was seen to lock up), e.g. to log it.
+GLOO_ON_DEVICE_TENSORS = os.environ.get("HMX_GLOO_DEVICE_TENSORS", "0") == "1"
+
+
 class _Done:
     def wait(self):
         return True
@@ -45,7 +50,7 @@ class _Done:
 def _host_staged(group, t) -> bool:
     """gloo with GPU tensors (tests and rehearsals with several ranks on one GPU): collectives go through host copies
     and finish before returning; gloo's own handling of GPU tensors was seen to lock up now and then there."""
-    return t.is_cuda and dist.get_backend(group) == "gloo"
+    return t.is_cuda and dist.get_backend(group) == "gloo" and not GLOO_ON_DEVICE_TENSORS
 
 
 def _all_gather_flat(out, t, group, async_op=False):

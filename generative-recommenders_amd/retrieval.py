@@ -12,6 +12,11 @@ import torch
 import torch.distributed as dist
 
 
+def _gloo_on_device():
+    from . import parallel
+    return parallel.GLOO_ON_DEVICE_TENSORS
+
+
 def shard_bounds(n_rows, world_size, rank):
     """Rows [lo, hi) of the table owned by `rank` (contiguous, ceil-divided; trailing ranks may be empty)."""
     per = -(-n_rows // world_size)
@@ -130,7 +135,7 @@ class ShardedRetriever:
         GPU): the tensor is copied to the host, gathered there and copied back, all before returning -- gloo's own
         handling of GPU tensors (helper threads that copy and synchronise streams) was seen to lock up now and then
         with two processes on one GPU, asynchronous or not."""
-        staged = dist.get_backend(self.group) == "gloo" and t.is_cuda
+        staged = dist.get_backend(self.group) == "gloo" and t.is_cuda and not _gloo_on_device()
         src = t.cpu() if staged else t
         out = torch.empty((self.world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
         try:
@@ -145,7 +150,7 @@ class ShardedRetriever:
         """(S, n, w) -> (S, n, w): block j of the result is what the j-th rank of this rank's query group sent in ITS
         block number shard_index.  One all_to_all_single over the whole group of ranks with zero-length messages
         between ranks of different query groups (no sub-communicators to create).  Same staging rule as _all_gather."""
-        staged = dist.get_backend(self.group) == "gloo" and send.is_cuda
+        staged = dist.get_backend(self.group) == "gloo" and send.is_cuda and not _gloo_on_device()
         src = send.cpu() if staged else send
         out = torch.empty_like(src)
         S, n, w = src.shape
