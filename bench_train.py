@@ -190,7 +190,7 @@ def run_train(args, world, rank, with_cpu_baseline=True):
     sb_ms, sb_n = spans["scan_bwd"]
     scan_gbs = scan_bytes * args.steps / (sb_ms * 1e-3) / 1e9 if sb_ms > 0 else 0.0
     scan_traffic = None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_scan_bwd_pmc.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_scan_bwd_pmc.json")
     if (B, L, d) == (1024, 100, 64) and os.path.exists(pmc):
         with open(pmc) as f:
             scan_traffic = json.load(f).get("hbm_bytes_per_launch")
@@ -288,7 +288,7 @@ def run_train(args, world, rank, with_cpu_baseline=True):
         "roofline": {"bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": scan_gbs / HBM_PEAK_GBS, "traffic": scan_traffic,
                      "traffic_unit": "HBM bytes per launch, mean over the step's six launches (FETCH_SIZE x 2 + WRITE_SIZE, "
-                                     "profiles/r02_scan_bwd_pmc.json)",
+                                     "profiles/r03_scan_bwd_pmc.json)",
                      "kernel": "scan_bwd_kernel (the step's longest kernel; its pace is set by the exp / fma work of the "
                                "recomputed recurrence, not by memory)",
                      "launches": sb_n, "avg_launch_ms": sb_ms / max(sb_n, 1),
