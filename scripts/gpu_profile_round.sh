@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round profile set: default bench line, kernel stats of both workloads, retrieval counter passes, configs[4] line.
+# Round profile set: default bench line, kernel stats of both workloads, retrieval counter passes, configs[4] line and kernel stats.
 # usage: gpu_profile_round.sh <part>   (a = default line + retrieval stats + counters, b = train stats + configs[4])
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r2
+OUT=$PWD/gpurun_out/r3
 mkdir -p $OUT
 set -e
 if [ "$1" = "a" ]; then
@@ -19,4 +19,6 @@ else
   python3 scripts/kernel_groups.py $OUT/prof_train 6 12
   timeout -k 10 500 python3 -u bench.py --workload train --batch 512 --seq-len 512 --dim 128 --steps 5 --warmup 2 > $OUT/train_config4.json 2> $OUT/train_config4.err
   tail -n 1 $OUT/train_config4.json | cut -c1-300
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_c4 -- python3 bench.py --workload train --batch 512 --seq-len 512 --dim 128 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_train_c4.log 2>&1
+  python3 scripts/kernel_groups.py $OUT/prof_train_c4 6 12
 fi

@@ -2,7 +2,7 @@
 # HBM traffic counters of the scatter-add kernels (16,777,216 uniform ids into 4,000,001 x 64), one run per counter group.
 set -e
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r2
+OUT=$PWD/gpurun_out/r3
 mkdir -p $OUT
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcs_fetch -- python3 scripts/pmc_scatter.py > $OUT/pmcs_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcs_write -- python3 scripts/pmc_scatter.py > $OUT/pmcs_write.log 2>&1

@@ -12,7 +12,7 @@ from collections import defaultdict
 path = sys.argv[1]
 steps = float(sys.argv[2])
 topn = int(sys.argv[3]) if len(sys.argv) > 3 else 25
-groups = {"hmx sort": ["radix_"], "scan": ["scan_"], "linear": ["linear_kernel"], "wgrad": ["wgrad"],
+groups = {"input assembly": ["input_assembly"], "hmx sort": ["radix_"], "scan": ["scan_"], "linear": ["linear_kernel"], "wgrad": ["wgrad"],
           "fused block": ["ffn_", "pre_", "post_", "block_"], "loss (nce + its run sums)": ["nce_", "WeightedRows", "inv_norm"],
           "optimizer + clip": ["adamw_kernel", "adamw_table", "table_sumsq", "grad_sumsq", "grad_norm_finish", "multi_tensor", "fused_adam", "FusedAdam"],
           "rocprim (nonzero, scans)": ["rocprim", "ROCPRIM"], "top-k (miner)": ["coarse", "rescore", "seed_thr", "to_bf16", "warm", "group_max", "group_threshold"],
