@@ -20,6 +20,7 @@ from .enc_ops import pscan, selective_scan   # noqa: F401  (hydra3.py:104, 107: 
 from .shared_embedding import SharedEmbeddingConfig, SharedEmbeddingModule
 
 D_STATE, DT_RANK, D_CONV = 16, 16, 4
+ALIGN_LOSS_ROWS = True          # the loss pads rows whose width is not a multiple of 16 floats (see compute_mixed_contrastive_loss)
 FUSED_INPUT_ASSEMBLY = True     # log2feats builds its input with hmx_input_assembly_fwd where the widths allow
 VALIDATE_HARD_GROUPS = False   # debug switch: verify on the device that broadcast hard-negative lists repeat per sequence
 FUSED_BLOCKS = True      # HydraBlock(First) on the fused block kernels where block_ops.Layout.of(d, heads) exists (d <= 128 after widening)
@@ -406,6 +407,7 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
     hard_ids = None
     hard_groups = None
     n_hard_slots = None
+    per_sequence = False
     if hard_negatives is not None and num_hard > 0:                      # hydra3.py:905-919
         per_sequence = hard_negatives.dim() == 3 and hard_negatives.stride(1) == 0
         if per_sequence:                          # one list per sequence, broadcast over its positions
@@ -456,7 +458,20 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
                     hard_ids = rid if hard_ids is None else torch.cat([hard_ids, rid], dim=1)
                 else:
                     inb = torch.cat([inb, inb[:, -1:].expand(-1, short)], dim=1)
-    return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize, hard_groups=hard_groups,
+    table = item_table
+    if ALIGN_LOSS_ROWS and q.is_cuda and d % 16 and hard_groups is not None and per_sequence:
+        # Rows of a width that is not a multiple of 64 bytes (the reference's default d = 60: 240-byte rows) straddle
+        # cache lines, and the loss is two walks over 36 M such rows.  Same loss on rows widened with zero columns: q
+        # and k are padded, and the hard negatives -- one list of K ids per sequence -- are gathered once into a small
+        # padded table of B * K rows that the loss indexes instead (row b * K + j = item row of sequence b's j-th id);
+        # its gradient returns through the gather's scatter-add.  Zero columns change neither norms nor dot products.
+        pad = (0, (d + 15) // 16 * 16 - d)
+        q, k = F.pad(q, pad), F.pad(k, pad)
+        lists = hard_negatives[:, 0]                                     # (B, K) ids
+        table = F.pad(ops.gather_rows(item_table, lists.reshape(-1)), pad)
+        K = lists.shape[1]
+        hard_ids = (seq_of_row * K).unsqueeze(1) + torch.arange(K, device=device).unsqueeze(0)
+    return ops.fused_nce_rows(q, k, table, hard_ids, inb, temperature, normalize, hard_groups=hard_groups,
                               n_hard=n_hard_slots, inb_skip_self=skip_self).mean()
 
 

@@ -359,12 +359,42 @@ def test_zero_weight_loss_terms_can_be_evaluated_like_the_reference_does():
         loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"], bt["act"],
                  bt["dwell"])
         loss.backward()
-        results.append((float(loss), {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}))
+        results.append((float(loss.detach()), {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}))
     (l0, g0), (l1, g1) = results
     assert l0 == l1
     assert set(g0) == set(g1)
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+
+
+def test_loss_on_padded_rows_equals_loss_on_240_byte_rows():
+    """At widths that are not a multiple of 16 floats (the reference's default 60) the loss runs on rows padded with
+    zero columns and on a small gathered table of the sequences' hard negatives; same step, same seed: the loss and
+    every gradient agree with the unpadded path to fp32 rounding."""
+    from generative_recommenders_amd import synth
+    U, I, d, L, B = 200, 1500, 60, 12, 6
+    m = H.build_model(U, I, d=d, L=L, dropout=0.0, device=DEV, seed=3).train()
+    bt = synth.train_batch(B, L, U, I, DEV, seed=4)
+    feat = [[] for _ in range(B)]
+    results = []
+    old = H.ALIGN_LOSS_ROWS
+    try:
+        for flag in (False, True):
+            H.ALIGN_LOSS_ROWS = flag
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(77)
+            loss = m(bt["seq"], bt["pos"], bt["neg"], bt["tok"], bt["next_tok"], None, feat, feat, feat, bt["ts"],
+                     bt["act"], bt["dwell"])
+            loss.backward()
+            results.append((float(loss.detach()), {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}))
+    finally:
+        H.ALIGN_LOSS_ROWS = old
+    (l0, g0), (l1, g1) = results
+    assert abs(l0 - l1) <= 2e-6 * abs(l0)
+    assert set(g0) == set(g1)
+    for k in g0:
+        scale = float(g0[k].abs().max()) + 1e-30
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * scale, k
 
 
 def test_input_assembly_entry_point_rejects_unsupported_shapes():
