@@ -62,8 +62,8 @@ struct WeightedRows {
     const float* coef;      // (n_src, coef_stride)
     int per_row, coef_stride, col0;
     __device__ __forceinline__ Val make_val(int64_t e) const {
-        const int64_t i = e / per_row, sidx = e - i * per_row;
-        return make_uint2((uint32_t)i, __float_as_uint(coef[i * coef_stride + col0 + sidx]));
+        const uint32_t i = (uint32_t)e / (uint32_t)per_row, sidx = (uint32_t)e - i * (uint32_t)per_row;   // e < 2^32 (checked by the sort): no 64-bit division
+        return make_uint2(i, __float_as_uint(coef[(int64_t)i * coef_stride + col0 + sidx]));
     }
     __device__ __forceinline__ int64_t row_index(Val v) const { return (int64_t)v.x; }
     template <class V>
