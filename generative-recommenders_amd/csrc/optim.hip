@@ -273,6 +273,12 @@ __global__ __launch_bounds__(kThreads) void adamw_table_kernel(TableList tl, Ada
                     n2 = p4[u].x * p4[u].x + p4[u].y * p4[u].y + p4[u].z * p4[u].z + p4[u].w * p4[u].w;
                 }
             }
+            else if (t.bf16_out != nullptr && r[u] < t.n_rows && rr + u * rows_per_pass < kTableRows && lane_c >= cpr &&
+                     4 * lane_c < t.bf16_ld) {
+                // a lane past the row's width: it writes the zero columns of the copy's padded row, so that the row
+                // leaves as whole cache lines (120 of 128 bytes at d = 60 made every line a partial write)
+                *reinterpret_cast<uint2*>(t.bf16_out + r[u] * t.bf16_ld + 4 * lane_c) = make_uint2(0u, 0u);
+            }
             if (t.bf16_out != nullptr) {     // row norm: over the lpr lanes of the row (wave-uniform branch)
                 for (int off = lpr >> 1; off > 0; off >>= 1) n2 += __shfl_xor(n2, off);
                 best = fmaxf(best, n2);
