@@ -126,10 +126,13 @@ struct EntriesFromIds {
 // One workgroup owns one block of kSuper sorted entries.  Its keys and values are read once into LDS; the
 // wave ballots of "differs from the entry before" give every piece its number and extent (one entry in the
 // list per distinct row of the block).  The source rows -- a random 4 * d bytes each, the bulk of the traffic --
-// come in through the LDS DMA path in sub-blocks of S entries, double-buffered: while the groups of lpr lanes
-// walk the pieces of sub-block k out of LDS, the rows of sub-block k + 1 are in flight, 32 KB per workgroup and no
-// registers held.  A piece that crosses a sub-block boundary hands its running sum to the next sub-block through
-// a carry row, so its additions still happen one after the other in entry order.
+// come in through the LDS DMA path in sub-blocks of S entries (32 KB, no registers held) into ONE stage per
+// workgroup; the table rows of the sub-block's whole runs are requested just before its DMA, so one memory round
+// trip serves both.  Overlap comes from the four workgroups a CU holds, not from a second stage: walking a
+// sub-block out of LDS takes a fraction of its round trip, so about four fifths of the CU's stage bytes are in
+// flight at any time (two stages per workgroup keep half of them in flight: measured 8 % slower on uniform ids,
+// 20 % on Zipf ids).  A piece that crosses a sub-block boundary hands its running sum to the next sub-block
+// through a carry row, so its additions still happen one after the other in entry order.
 constexpr int kSuper = 512;
 constexpr int kStageBytes = 32 * 1024;
 
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
     using V = typename VecT<VEC>::type;
     using Val = typename Src::Val;
     constexpr int CH = VEC * 4;               // bytes per lane per DMA instruction
-    extern __shared__ __attribute__((aligned(1024))) char smem[];   // two stages, then two carry rows
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // the stage, then two carry rows
     __shared__ uint32_t keyL[kSuper + 1];     // [nb] holds the key after the block
     __shared__ Val valL[kSuper];
     __shared__ uint16_t piece_start[kSuper + 2];   // 16-bit lists: two workgroups of the 8-byte-value form fit a CU
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
     __syncthreads();
 
     // piece list: an entry starts a piece when its key differs from the entry before it, or when it is the first
-    // of a sub-block (so that no piece spans two stages; the carry row joins the halves again)
+    // of a sub-block (so that no piece spans two sub-blocks; the carry row joins the halves again)
     bool my_start[2];
     int my_rank[2];
 #pragma unroll
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
     // f % cpr of entry f / cpr; a wave's instruction covers 64 consecutive chunks and lands them dense in LDS.
     const int q0 = tid / cpr, r0 = tid % cpr, step_q = kBlock / cpr, step_r = kBlock % cpr;
     auto issue = [&](int k) {
-        char* st = smem + (k & 1) * stage_bytes;
+        char* st = smem;
         const int e0 = k * S;
         const int cnt = (n_valid - e0 < S) ? n_valid - e0 : S;
         const int total = cnt * cpr;
@@ -239,12 +242,11 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
 
     const int lpr = 1 << lpr_log2;
     const int lane_c = tid & (lpr - 1), grp = tid >> lpr_log2, n_groups = kBlock >> lpr_log2;
-    V* carry = reinterpret_cast<V*>(smem + 2 * stage_bytes);   // [2][cpr]
-    issue(0);
+    const int cpr_up = (cpr + lpr - 1) & ~(lpr - 1);
+    V* carry = reinterpret_cast<V*>(smem + stage_bytes);   // [2][cpr]
     for (int k = 0; k < n_sub; ++k) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of sub-block k is in LDS
-        __syncthreads();                                    // everyone's is, and sub-block k - 1 has been consumed
-        const V* st = reinterpret_cast<const V*>(smem + (k & 1) * stage_bytes);
+        __syncthreads();                                    // sub-block k - 1 has been consumed: the stage may be overwritten
+        const V* st = reinterpret_cast<const V*>(smem);
         const int e0 = k * S;
         // U pieces per trip: their table rows are requested first (and before the next stage's DMA, which would
         // otherwise queue ahead of them), then each piece is summed out of LDS while those reads are in flight.
@@ -267,22 +269,27 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
                 starts_true[u] = continues[u] ? (carry_flag[(k - 1) & 1] != 0) : (s_pos[u] > 0 || key_before != key[u]);
                 whole[u] = live[u] && !goes_on[u] && starts_true[u] && keyL[e_pos[u]] != key[u];
             }
-            for (int c = lane_c; c < cpr; c += lpr) {
+            // every lane walks the padded row width, so the first trip's first chunk is one point that each wave passes
+            // exactly once per stage, whatever the row width: the DMA is issued there (and, with one buffer, awaited)
+            for (int c = lane_c; c < cpr_up; c += lpr) {
+                const bool ok = c < cpr;
                 V cur[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     cur[u] = vzero<VEC>();
-                    if (whole[u]) cur[u] = (reinterpret_cast<const V*>(grad_table) + (int64_t)key[u] * cpr)[c];
+                    if (whole[u] && ok) cur[u] = (reinterpret_cast<const V*>(grad_table) + (int64_t)key[u] * cpr)[c];
                 }
                 asm volatile("" ::: "memory");
-                if (!dma_issued && c == lane_c) {          // wave-uniform: every wave passes here exactly once per stage
-                    if (k + 1 < n_sub) issue(k + 1);
+                if (!dma_issued) {
+                    issue(k);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the sub-block is in LDS
+                    __syncthreads();                                    // everyone's is
                     dma_issued = true;
                     asm volatile("" ::: "memory");
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (!live[u]) continue;
+                    if (!live[u] || !ok) continue;
                     V acc = continues[u] ? carry[((k - 1) & 1) * cpr + c] : vzero<VEC>();
                     const V* rowp = st + (s_pos[u] - e0) * cpr + c;
                     int e = s_pos[u];
@@ -315,10 +322,6 @@ __global__ __launch_bounds__(kBlock) void segment_sum_staged_kernel(Src src, con
                         reinterpret_cast<V*>(tail_piece)[sb * cpr + c] = acc;
                     }
                 }
-            }
-            if (!dma_issued) {                             // lanes beyond the row width (lane_c >= cpr) never enter the c loop
-                if (k + 1 < n_sub) issue(k + 1);
-                dma_issued = true;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -559,7 +562,7 @@ inline int sort_bits(int64_t n_rows) {
 }
 
 constexpr int kMaxRowFloats = kStageBytes / 4;      // one row must fit an LDS stage
-constexpr int kMaxStagedLds = 2 * kStageBytes + 2 * kStageBytes;   // two stages + two carry rows at the widest row
+constexpr int kMaxStagedLds = kStageBytes + 2 * kStageBytes;   // one stage + two carry rows at the widest row
 
 inline size_t piece_bytes(int64_t n, int64_t d, int piece) {
     return hmx_align_up((size_t)hmx_ceil_div(n, piece) * (size_t)d * sizeof(float), 256);
@@ -612,7 +615,7 @@ int sorted_segment_add(const Src& src, bool vec, const IdSource& ids, const int6
     const int row_bytes = (int)d * 4;
     const int S = std::max(1, std::min(kBlock, std::max(kStageBytes, row_bytes) / row_bytes));   // entries per LDS stage
     const int stage_bytes = (int)hmx_align_up((size_t)S * row_bytes, 1024);
-    const int lds = 2 * stage_bytes + 2 * (int)hmx_align_up((size_t)row_bytes, 16);
+    const int lds = stage_bytes + 2 * (int)hmx_align_up((size_t)row_bytes, 16);
     const int grid3 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid * 4);
     const int grid4 = (int)std::min<int64_t>(hmx_ceil_div(n_sb, kBlock >> l2), (int64_t)kMaxGrid);
     auto run = [&](auto vec_tag) {
