@@ -96,7 +96,7 @@ int hmx_scatter_add_rows_f32(const float* grad_rows, const int64_t* ids, const i
  * The sort keys, their sorted copies, the run pieces and the sort's digit counters live in a fixed array of
  * hmx_scatter_add_rows_static_scratch_bytes() (16 MiB) inside the library, one copy per GPU, held until the process
  * ends; the call allocates nothing.  Inputs whose hmx_scatter_add_rows_workspace_bytes(n, n_rows, d) exceeds that
- * size (about 1,000,000 ids at d = 64) are refused with HMX_ELIMIT and nothing is enqueued.  Result: bit-identical to
+ * size (about 880,000 ids at d = 64) are refused with HMX_ELIMIT and nothing is enqueued.  Result: bit-identical to
  * hmx_scatter_add_rows_f32.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
  * (different streams or threads) race; calls on one stream, or on different GPUs, do not.
  * The first call on a GPU looks up the array's address and raises two kernels' dynamic-LDS limits (HIP module
