@@ -251,6 +251,7 @@ int colsum_chunks(int64_t rows, int64_t cols) {
 }
 
 // ---------------------------------------------------------------------------- linear (bf16 MFMA)
+constexpr int kLinearMaxHeads = 8;
 struct LinearParams {
     const float* X;
     int64_t ldx;
@@ -270,6 +271,11 @@ struct LinearParams {
     const float* in_rowmask;   // (T) or null: X row scaled before the product
     const float* out_rowmask;  // (T) or null: Y row scaled after everything else
     int accumulate;            // Y = Y_old + result
+    // block-diagonal form (n_heads > 0): head h = blockIdx.z multiplies columns [h * x_hs, h * x_hs + K) of X by its
+    // own weight Wh[h] into columns [h * y_hs, h * y_hs + N) of Y -- all heads of a projection in one launch
+    int n_heads;
+    int64_t x_hs, y_hs;
+    const float* Wh[kLinearMaxHeads];
 };
 
 // SPLIT = false: one bf16 MFMA per product (inputs rounded to bf16, relative error ~2^-9 per operand).
@@ -281,12 +287,21 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
     constexpr int KP = KS * 16 + 8;  // bf16 elements per LDS row (+8 keeps ds_read_b128 conflict-free)
     uint16_t* wl = reinterpret_cast<uint16_t*>(smem);
     uint16_t* wl_lo = wl + (size_t)p.n_chunk * KP;
+    const float* __restrict__ Wm = p.W;
+    const float* __restrict__ Xm = p.X;
+    float* __restrict__ Ym = p.Y;
+    if (p.n_heads > 0) {
+        const int hd = blockIdx.z;
+        Wm = p.Wh[hd];
+        Xm += hd * p.x_hs;
+        Ym += hd * p.y_hs;
+    }
     const int n_base = blockIdx.y * p.n_chunk;
     const int nc = min(p.n_chunk, p.N - n_base);
     const int npad = (nc + 31) / 32 * 32;
     for (int idx = threadIdx.x; idx < npad * KS * 16; idx += 256) {
         const int n = idx / (KS * 16), k = idx % (KS * 16);
-        const float v = (n < nc && k < p.K) ? p.W[(int64_t)(n_base + n) * p.w_rs + (int64_t)k * p.w_cs] : 0.f;
+        const float v = (n < nc && k < p.K) ? Wm[(int64_t)(n_base + n) * p.w_rs + (int64_t)k * p.w_cs] : 0.f;
         const uint16_t hi = (uint16_t)hmx_pack_bf16x2(v, 0.f);
         wl[n * KP + k] = hi;
         if (SPLIT) wl_lo[n * KP + k] = (uint16_t)hmx_pack_bf16x2(v - hmx_bf16_to_f32(hi), 0.f);
@@ -298,7 +313,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
         const int64_t t = tile * 32 + i;
         const bool ok = t < p.T;
         const float im = (ok && p.in_rowmask) ? p.in_rowmask[t] : 1.f;
-        const float* xr = p.X + (ok ? t : 0) * p.ldx;
+        const float* xr = Xm + (ok ? t : 0) * p.ldx;
         short8 a[KS], a_lo[SPLIT ? KS : 1];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
         const bool t_ok = tt < p.T;
         const float om = (t_ok && p.out_rowmask) ? p.out_rowmask[tt] : 1.f;
         const bool vec_ok = ((p.ldy | p.ldr1 | p.ldr2) & 3) == 0 &&
-                            ((reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.R1) |
+                            ((reinterpret_cast<uintptr_t>(Ym) | reinterpret_cast<uintptr_t>(p.R1) |
                               reinterpret_cast<uintptr_t>(p.R2) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
         for (int nt = 0; nt < npad / 32; ++nt) {
             f32x16 acc;
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
                 const int n0 = n_base + nt * 32 + 8 * q + 4 * h;
                 if (n0 >= n_base + nc) continue;
                 float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                float* dst = p.Y + tt * p.ldy + n0;
+                float* dst = Ym + tt * p.ldy + n0;
                 if (vec_ok && n0 + 4 <= n_base + nc && (n0 & 3) == 0) {
                     if (p.bias) {
                         const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0);
@@ -1339,15 +1354,8 @@ static void launch_linear(int ks, dim3 grid, size_t lds, hipStream_t s, const Li
     }
 }
 
-extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, int64_t w_cs,
-                              const float* bias, int64_t T, int64_t N, int64_t K, float* Y, int64_t ldy,
-                              const float* R1, int64_t ldr1, float c1, const float* R2, int64_t ldr2, float c2,
-                              const float* in_rowmask, const float* out_rowmask, int accumulate, void* stream) {
-    HMX_ENTER();
-    if (T == 0 || N == 0) return HMX_OK;
-    if (!X || !W || !Y || K <= 0 || K > 256 || N < 0 || N > 65535) return HMX_EINVAL;
-    LinearParams p{X, ldx, W, w_rs, w_cs, bias, T, (int)N, (int)K, 0, Y, ldy, R1, ldr1, c1, R2, ldr2, c2,
-                   in_rowmask, out_rowmask, accumulate};
+static int linear_launch(LinearParams& p, int n_z, hipStream_t stream) {
+    const int64_t T = p.T, N = p.N, K = p.K;
     const int ks = ks_for((int)K);
     const int kp = ks * 16 + 8;
     const int copies = g_linear_split ? 2 : 1;
@@ -1365,13 +1373,43 @@ extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64
         const int64_t cap = std::max<int64_t>(64, 512 / n_panels);
         gx = hmx_ceil_div(groups, hmx_ceil_div(groups, cap));
     }
-    const dim3 grid((unsigned)gx, (unsigned)n_panels);
+    const dim3 grid((unsigned)gx, (unsigned)n_panels, (unsigned)n_z);
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
     if (g_linear_split) launch_linear<true>(ks, grid, lds, (hipStream_t)stream, p);
     else launch_linear<false>(ks, grid, lds, (hipStream_t)stream, p);
     hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
+}
+
+extern "C" int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, int64_t w_cs,
+                              const float* bias, int64_t T, int64_t N, int64_t K, float* Y, int64_t ldy,
+                              const float* R1, int64_t ldr1, float c1, const float* R2, int64_t ldr2, float c2,
+                              const float* in_rowmask, const float* out_rowmask, int accumulate, void* stream) {
+    HMX_ENTER();
+    if (T == 0 || N == 0) return HMX_OK;
+    if (!X || !W || !Y || K <= 0 || K > 256 || N < 0 || N > 65535) return HMX_EINVAL;
+    LinearParams p{X, ldx, W, w_rs, w_cs, bias, T, (int)N, (int)K, 0, Y, ldy, R1, ldr1, c1, R2, ldr2, c2,
+                   in_rowmask, out_rowmask, accumulate, 0, 0, 0, {}};
+    return linear_launch(p, 1, (hipStream_t)stream);
+}
+
+// Y[:, h * y_head_stride + (0..N)] (+)= X[:, h * x_head_stride + (0..K)] Wv_h^T for h < n_heads in ONE launch; W: host
+// array of n_heads device pointers, each viewed as Wv_h(n, k) = W[h][n * w_rs + k * w_cs].
+extern "C" int hmx_heads_linear_f32(const float* X, int64_t ldx, int64_t x_head_stride, const float* const* W,
+                                    int64_t w_rs, int64_t w_cs, int64_t T, int64_t N, int64_t K, float* Y, int64_t ldy,
+                                    int64_t y_head_stride, int n_heads, int accumulate, void* stream) {
+    HMX_ENTER();
+    if (T == 0 || N == 0 || n_heads == 0) return HMX_OK;
+    if (!X || !W || !Y || K <= 0 || K > 256 || N < 0 || N > 65535 || n_heads < 0 || n_heads > kLinearMaxHeads)
+        return HMX_EINVAL;
+    LinearParams p{X, ldx, nullptr, w_rs, w_cs, nullptr, T, (int)N, (int)K, 0, Y, ldy, nullptr, 0, 0.f, nullptr, 0, 0.f,
+                   nullptr, nullptr, accumulate, n_heads, x_head_stride, y_head_stride, {}};
+    for (int h = 0; h < n_heads; ++h) {
+        if (!W[h]) return HMX_EINVAL;
+        p.Wh[h] = W[h];
+    }
+    return linear_launch(p, n_heads, (hipStream_t)stream);
 }
 
 // Token splits of a weight-gradient launch: four per workgroup (one per wave).  Two workgroups fit a CU, so the chip

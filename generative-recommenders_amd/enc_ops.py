@@ -2,6 +2,7 @@
 
 All tensors are CUDA fp32; token-major (T, features).  No CPU fallback.
 """
+import ctypes
 import math
 
 import torch
@@ -263,6 +264,16 @@ def _linear_raw(x_ptr, ldx, w_ptr, w_rs, w_cs, bias, T, N, K, y_ptr, ldy, r1=Non
               "hmx_linear_f32")
 
 
+def _heads_linear_raw(x_ptr, ldx, x_hs, ws, w_rs, w_cs, T, N, K, y_ptr, ldy, y_hs, accumulate=False):
+    """All heads of a block-diagonal projection in one launch (hmx_heads_linear_f32); ws: one weight tensor per head."""
+    for h0 in range(0, len(ws), 8):               # the launch takes up to eight heads
+        part = ws[h0:h0 + 8]
+        ptrs = (ctypes.c_void_p * len(part))(*[w.data_ptr() for w in part])
+        hmx.check(_L().hmx_heads_linear_f32(x_ptr + 4 * h0 * x_hs, ldx, x_hs, ptrs, w_rs, w_cs, T, N, K,
+                                            y_ptr + 4 * h0 * y_hs, ldy, y_hs, len(part), 1 if accumulate else 0, _s()),
+                  "hmx_heads_linear_f32")
+
+
 def _wgrad_raw(dy_ptr, ldy, x_ptr, ldx, in_mask, T, N, K, dw_ptr, ldw, db, device):
     ws = workspace(_L().hmx_linear_wgrad_workspace_bytes(T, N, K), device)
     hmx.check(_L().hmx_linear_wgrad_f32(dy_ptr, ldy, x_ptr, ldx, hmx.ptr(in_mask), T, N, K, dw_ptr, ldw, hmx.ptr(db),
@@ -347,9 +358,7 @@ class _HeadsLinear(torch.autograd.Function):
         T = x.shape[0]
         assert x.shape[1] == H * k_in
         y = _empty(T, H * n_out, like=x)
-        for h, w in enumerate(ws):
-            _linear_raw(x.data_ptr() + 4 * h * k_in, H * k_in, hmx.ptr(w), k_in, 1, None, T, n_out, k_in,
-                        y.data_ptr() + 4 * h * n_out, H * n_out)
+        _heads_linear_raw(x.data_ptr(), H * k_in, k_in, ws, k_in, 1, T, n_out, k_in, y.data_ptr(), H * n_out, n_out)
         ctx.save_for_backward(x, *ws)
         ctx.params, ctx.rows = params, (r0, r1)
         return y
@@ -364,11 +373,10 @@ class _HeadsLinear(torch.autograd.Function):
         r0, r1 = ctx.rows
         dx = _empty(T, H * k_in, like=x) if ctx.needs_input_grad[0] else None
         dws = []
+        if dx is not None:
+            _heads_linear_raw(g.data_ptr(), H * n_out, n_out, ws, 1, k_in, T, k_in, n_out, dx.data_ptr(), H * k_in, k_in)
         for h, w in enumerate(ws):
             gp = g.data_ptr() + 4 * h * n_out
-            if dx is not None:
-                _linear_raw(gp, H * n_out, hmx.ptr(w), 1, k_in, None, T, k_in, n_out, dx.data_ptr() + 4 * h * k_in,
-                            H * k_in)
             if not ctx.needs_input_grad[3 + h]:
                 dws.append(None)
                 continue
@@ -626,9 +634,7 @@ class _ProjScan(torch.autograd.Function):
         if ED < 32 or ED & (ED - 1) or C != ED * H or len(ws) != H or any(w.shape != (P_DBC, EDr) for w in ws):
             raise hmx.HmxError(f"selective scan needs 4*head_dim to be a power of two >= 32 (got {ED})")
         dbc = _empty(T, H * P_DBC, like=xc)
-        for h, w in enumerate(ws):
-            _linear_raw(xc.data_ptr() + 4 * h * ED, C, hmx.ptr(w), EDr, 1, None, T, P_DBC, EDr,
-                        dbc.data_ptr() + 4 * h * P_DBC, H * P_DBC)
+        _heads_linear_raw(xc.data_ptr(), C, ED, ws, EDr, 1, T, P_DBC, EDr, dbc.data_ptr(), H * P_DBC, P_DBC)
         keep = any(ctx.needs_input_grad)
         hs = _empty(max(int(_L().hmx_scan_state_floats(B, L, C)), 1), like=xc) if keep else None
         yg = torch.empty_like(xc)
@@ -661,10 +667,10 @@ class _ProjScan(torch.autograd.Function):
             hmx.check(_L().hmx_sum_groups_f32(hmx.ptr(dpart), T * H, gph, P_DBC, hmx.ptr(ddbc), _s()),
                       "hmx_sum_groups_f32")
         dws = []
+        _heads_linear_raw(ddbc.data_ptr(), H * P_DBC, P_DBC, ws, 1, EDr, T, EDr, P_DBC, dxc.data_ptr(), C, ED,
+                          accumulate=True)
         for h, w in enumerate(ws):
             gp = ddbc.data_ptr() + 4 * h * P_DBC
-            _linear_raw(gp, H * P_DBC, hmx.ptr(w), 1, EDr, None, T, EDr, P_DBC, dxc.data_ptr() + 4 * h * ED, C,
-                        accumulate=True)
             if not ctx.needs_input_grad[10 + h]:
                 dws.append(None)
                 continue

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "hmx_colsum_f32": (c_int, [P, I64, I64, I64, P, P, c_size_t, P]),
     "hmx_set_linear_precision": (c_int, [c_int]),
     "hmx_linear_f32": (c_int, [P, I64, P, I64, I64, P, I64, I64, I64, P, I64, P, I64, F, P, I64, F, P, P, c_int, P]),
+    "hmx_heads_linear_f32": (c_int, [P, I64, I64, P, I64, I64, I64, I64, I64, P, I64, I64, c_int, c_int, P]),
     "hmx_linear_wgrad_workspace_bytes": (c_size_t, [I64, I64, I64]),
     "hmx_linear_wgrad_f32": (c_int, [P, I64, P, I64, P, I64, I64, I64, P, I64, P, P, c_size_t, P]),
     "hmx_linear_wgrad_batch_workspace_bytes": (c_size_t, [ctypes.POINTER(WgradDesc), I64]),

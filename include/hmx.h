@@ -295,6 +295,15 @@ int hmx_linear_f32(const float* X, int64_t ldx, const float* W, int64_t w_rs, in
                    const float* R2, int64_t ldr2, float c2, const float* in_rowmask, const float* out_rowmask,
                    int accumulate, void* stream);
 
+/* The per-head projections of the multi-head Mamba blocks (hydra3.py:156 deltaBC_layer, 243/248 in_proj / out_proj of
+ * every head in the hydra3.py:366 loop, and their input gradients) as ONE launch: head h < n_heads (<= 8) computes
+ *   Y[t, h * y_head_stride + n] (+)= sum_k X[t, h * x_head_stride + k] * Wv_h(n, k),  Wv_h(n, k) = W[h][n * w_rs + k * w_cs]
+ * with the precision of hmx_linear_f32.  W: HOST array of n_heads device pointers (the heads' weights are separate
+ * parameters).  accumulate != 0 adds to Y.  Same results as n_heads calls of hmx_linear_f32 on the column blocks. */
+int hmx_heads_linear_f32(const float* X, int64_t ldx, int64_t x_head_stride, const float* const* W, int64_t w_rs,
+                         int64_t w_cs, int64_t T, int64_t N, int64_t K, float* Y, int64_t ldy, int64_t y_head_stride,
+                         int n_heads, int accumulate, void* stream);
+
 /* Weight / bias gradient on fp32 MFMA: dW[n * ldw + k] = sum_t dY[t, n] * X[t, k] * in_rowmask[t],
  * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  A wave owns up to eight 32 x 32 output tiles and reads its operands
  * with vector loads where base, row stride and extent allow (16-byte aligned dY / X with ldy, ldx, N, K multiples of

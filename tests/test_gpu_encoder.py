@@ -109,6 +109,47 @@ def test_linear_kernel_vs_fp32(T, N, K):
     close(r1d.grad, rr.grad, 1e-6, 1e-6, "dr1")
 
 
+@pytest.mark.parametrize("T,H,N,K,xs,ys", [(1000, 4, 48, 64, 64, 48), (333, 4, 64, 48, 48, 64), (70, 3, 16, 60, 64, 16),
+                                            (129, 10, 32, 16, 16, 32), (5, 1, 128, 128, 128, 128)])
+def test_heads_linear_one_launch_equals_per_head_launches(T, H, N, K, xs, ys):
+    """hmx_heads_linear_f32 against hmx_linear_f32 on every head's column block: same bits, forward and transposed
+    (accumulating) form; through E.heads_linear also against fp32 matmuls."""
+    import ctypes
+    from generative_recommenders_amd import hmx
+    g = torch.Generator().manual_seed(T + H + N + K)
+    x = torch.randn(T, H * xs, generator=g).to(DEV)
+    ws = [(torch.randn(N, K, generator=g) / K ** 0.5).to(DEV) for _ in range(H)]
+    L, s = hmx.lib(), torch.cuda.current_stream().cuda_stream
+    for accumulate, transposed in ((0, False), (1, True)):
+        n_out, k_in = (K, N) if transposed else (N, K)
+        src = torch.randn(T, H * (ys if transposed else xs), generator=g).to(DEV) if transposed else x
+        s_hs, d_hs = (ys, xs) if transposed else (xs, ys)
+        w_rs, w_cs = (1, K) if transposed else (K, 1)
+        y0 = torch.randn(T, H * d_hs, generator=g).to(DEV)
+        y_one, y_per = y0.clone(), y0.clone()
+        for h0 in range(0, H, 8):
+            part = ws[h0:h0 + 8]
+            ptrs = (ctypes.c_void_p * len(part))(*[w.data_ptr() for w in part])
+            hmx.check(L.hmx_heads_linear_f32(src.data_ptr() + 4 * h0 * s_hs, src.shape[1], s_hs, ptrs, w_rs, w_cs, T, n_out,
+                                             k_in, y_one.data_ptr() + 4 * h0 * d_hs, y_one.shape[1], d_hs, len(part),
+                                             accumulate, s), "hmx_heads_linear_f32")
+        for h, w in enumerate(ws):
+            hmx.check(L.hmx_linear_f32(src.data_ptr() + 4 * h * s_hs, src.shape[1], w.data_ptr(), w_rs, w_cs, None, T, n_out,
+                                       k_in, y_per.data_ptr() + 4 * h * d_hs, y_per.shape[1], None, 0, 0.0, None, 0, 0.0,
+                                       None, None, accumulate, s), "hmx_linear_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(y_one, y_per)
+        for h, w in enumerate(ws):
+            blk = src[:, h * s_hs:h * s_hs + k_in].double().cpu()
+            ref = blk @ (w.double().cpu() if transposed else w.double().cpu().t())
+            if accumulate:
+                ref = ref + y0[:, h * d_hs:h * d_hs + n_out].double().cpu()
+            close(y_one[:, h * d_hs:h * d_hs + n_out], ref.float(), 1e-4, 1e-4, f"head {h}")
+    ptrs = (ctypes.c_void_p * 9)(*[ws[0].data_ptr()] * 9)
+    assert L.hmx_heads_linear_f32(x.data_ptr(), x.shape[1], xs, ptrs, K, 1, T, N, K, x.data_ptr(), x.shape[1], ys, 9, 0,
+                                  s) == -1          # HMX_EINVAL: more heads than one launch takes
+
+
 def _wgrad_case(T, N, K, dy_off=0, x_off=0, pad=0, bias=True, mask=True, groups=None, accumulate=True, seed=0):
     """One descriptor on column-slice views (offsets / row padding in floats) and its float64 answer."""
     from generative_recommenders_amd import hmx
