@@ -201,7 +201,7 @@ class _BlockPre(torch.autograd.Function):
         link.dm = None
         cos, sin = E.rope_tables(L, lay.hd, dev, pairs=lay.hdp // 2)
         rows = int(hmx.lib().hmx_block_scale_partial_rows(T))
-        dx, s, dx1, n, part = mk(T, d), mk(T, d), mk(T, d), mk(T, d), zeros(rows, d)   # a launch may write fewer rows
+        dx, s, dx1, n, part = mk(T, d), mk(T, d), mk(T, d), mk(T, d), mk(rows, d)   # the launch zeroes the rows its waves do not write
         a = _args(T, L, d, H, first, eps, packed, mask=mask, x=x, drop=drop, scale1=sc, b1=b, rope_cos=cos, rope_sin=sin,
                   dx_in=dx_in, dz=dz, dy2=dy2, dm=dm, dx=dx, s=s, dx1=dx1, n=n, dscale_part=part)
         hmx.check(hmx.lib().hmx_block_pre_bwd(ctypes.byref(a), hmx.current_stream()), "hmx_block_pre_bwd")
@@ -246,7 +246,7 @@ class _BlockPost(torch.autograd.Function):
         rows = int(hmx.lib().hmx_block_scale_partial_rows(T))
         dyg, dy2, dm = mk(T, C), mk(T, d), mk(T, d)
         hmid, n2, dg, du, pp, dy1 = mk(T, d), mk(T, d), mk(T, d), mk(T, d), mk(T, d), mk(T, d)
-        part = torch.zeros(rows, d, dtype=torch.float32, device=dev)      # a launch may write fewer rows
+        part = mk(rows, d)             # the launch zeroes the rows its waves do not write
         a = _args(T, L, d, H, first, eps, packed, mask=mask, yg=yg, y2=y2, scale2=sc2, m=m, rstd2=rstd2, dout=dout,
                   dyg=dyg, dy2=dy2, dm=dm, hmid=hmid, n2=n2, dg=dg, du=du, p=pp, dy1=dy1, dscale_part=part)
         hmx.check(hmx.lib().hmx_block_post_bwd(ctypes.byref(a), hmx.current_stream()), "hmx_block_post_bwd")

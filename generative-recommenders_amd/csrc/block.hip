@@ -264,7 +264,8 @@ struct BlockParams {
     float* du;
     float* p;
     float* dy1;
-    float* dscale_part;     // (waves, d)
+    float* dscale_part;     // (scale_rows, d): one row per wave of the launch, the rows past them zeroed by the launch
+    int scale_rows;
     // backward, pre half
     const float* dx_in;     // (T, C)
     const float* dz;        // (T, C)
@@ -273,6 +274,14 @@ struct BlockParams {
     float* dx1;
     float* n;
 };
+
+// The partial-sum buffer has a row for every wave of the largest launch; a smaller launch clears the rows its waves do
+// not write, so the caller sums all rows of an uninitialised buffer.
+__device__ __forceinline__ void zero_unwritten_scale_rows(const BlockParams& p, int waves_per_block) {
+    const int64_t first = (int64_t)gridDim.x * waves_per_block * p.lay.d, end = (int64_t)p.scale_rows * p.lay.d;
+    for (int64_t e = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < end; e += (int64_t)gridDim.x * blockDim.x)
+        p.dscale_part[e] = 0.f;
+}
 
 constexpr int kMaxNT = 4;   // d <= 128
 
@@ -752,6 +761,7 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_post_bwd_kernel(Bloc
         }
     }
     dsc.flush(p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
+    zero_unwritten_scale_rows(p, WPB);
 }
 
 // ------------------------------------------------------------------ pre half, backward
@@ -921,6 +931,7 @@ __global__ __launch_bounds__(64 * bwd_waves(NT)) void block_pre_bwd_kernel(Block
         }
     }
     dsc.flush(p.dscale_part + ((int64_t)blockIdx.x * WPB + wave) * d, lane);
+    zero_unwritten_scale_rows(p, WPB);
 }
 
 // ------------------------------------------------------------------ input assembly (hydra3.py:621-669)
@@ -1222,6 +1233,7 @@ static bool fill_common(BlockParams& p, const hmx_block_args* a) {
     p.rstd1 = a->rstd1; p.x_in = a->x_in; p.z = a->z; p.y2 = a->y2; p.yg = a->yg; p.b2 = a->b2; p.scale2 = a->scale2;
     p.out = a->out; p.m = a->m; p.rstd2 = a->rstd2; p.dout = a->dout; p.dyg = a->dyg; p.dy2 = a->dy2; p.dm = a->dm;
     p.hmid = a->hmid; p.n2 = a->n2; p.dg = a->dg; p.du = a->du; p.p = a->p; p.dy1 = a->dy1; p.dscale_part = a->dscale_part;
+    p.scale_rows = (int)hmx_block_scale_partial_rows(a->T);
     p.dx_in = a->dx_in; p.dz = a->dz; p.dx = a->dx; p.s = a->s; p.dx1 = a->dx1; p.n = a->n;
     if (d_real != a->d) {       // widened layout: the d-vectors come from the pack buffer (zero in the added features)
         const float* vec = reinterpret_cast<const float*>(p.pk + p.lay.vec);

@@ -234,13 +234,24 @@ __global__ __launch_bounds__(256) void colsum_chunks_kernel(const float* __restr
     __syncthreads();
     if (w == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int n_chunks, int64_t cols,
-                                                            float* __restrict__ out) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+// 64 columns per workgroup; sixteen waves take every sixteenth chunk each and the first adds their sums in wave order
+// (a narrow matrix has up to 1024 chunks: one wave walking them alone took 12 us)
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int n_chunks, int64_t cols,
+                                                             float* __restrict__ out) {
+    __shared__ float sums[16][64];
+    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 64 + l;
     float s = 0.f;
-    for (int r = 0; r < n_chunks; ++r) s += part[(int64_t)r * cols + c];
-    out[c] = s;
+    if (c < cols)
+        for (int r = g; r < n_chunks; r += 16) s += part[(int64_t)r * cols + c];
+    sums[g][l] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sums[i][l];
+        out[c] = t;
+    }
 }
 // chunks of rows so that about a thousand blocks run; none when the input is short
 int colsum_chunks(int64_t rows, int64_t cols) {
@@ -1369,7 +1380,7 @@ extern "C" int hmx_colsum_f32(const float* P, int64_t rows, int64_t cols, int64_
         hipLaunchKernelGGL(colsum_chunks_kernel, dim3((unsigned)hmx_ceil_div(cols, 64), (unsigned)n_used), dim3(256), 0,
                            (hipStream_t)stream, P, rows, cols, ld, rpc, part);
         HMX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)hmx_ceil_div(cols, 256)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)hmx_ceil_div(cols, 64)), dim3(1024), 0, (hipStream_t)stream,
                            part, n_used, cols, out);
         HMX_CHECK_LAUNCH();
         return HMX_OK;

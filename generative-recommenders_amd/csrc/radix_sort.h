@@ -118,24 +118,25 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     return base + incl - v;
 }
 
-// one workgroup per digit: its row of tile counts becomes the row of exclusive prefixes; totals[digit] = the sum
+// one workgroup per digit: its row of tile counts becomes the row of exclusive prefixes; totals[digit] = the sum.
+// The row is walked 256 counts at a time (neighbouring threads read neighbouring counts) with a running base.
 __global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restrict__ hist, int n_tiles,
                                                               uint32_t* __restrict__ totals) {
     __shared__ uint32_t wave_sums[kWaves];
     uint32_t* row = hist + (int64_t)blockIdx.x * n_tiles;
     const int tid = threadIdx.x;
-    const int per = (n_tiles + kThreads - 1) / kThreads;
-    const int lo = min(tid * per, n_tiles), hi = min(lo + per, n_tiles);
-    uint32_t sum = 0;
-    for (int i = lo; i < hi; ++i) sum += row[i];
-    uint32_t total;
-    uint32_t run = block_exclusive_scan(sum, wave_sums, &total);
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t v = row[i];
-        row[i] = run;
-        run += v;
+    uint32_t base = 0;
+    uint32_t next = tid < n_tiles ? row[tid] : 0;
+    for (int c0 = 0; c0 < n_tiles; c0 += kThreads) {
+        const uint32_t v = next;
+        const int i = c0 + tid;
+        next = i + kThreads < n_tiles ? row[i + kThreads] : 0;      // the next chunk is on its way during this scan
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, wave_sums, &total);
+        if (i < n_tiles) row[i] = base + ex;
+        base += total;
     }
-    if (tid == 0) totals[blockIdx.x] = total;
+    if (tid == 0) totals[blockIdx.x] = base;
 }
 
 template <class In, class Val, int ND, int IPT>

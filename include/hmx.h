@@ -463,7 +463,8 @@ int hmx_input_assembly_bwd(const hmx_input_assembly_args* a, void* stream);
  * The backward halves recompute the intermediates they need from (x, m, rstd2, yg, y2), write the input gradients
  * (dyg, dy2, dm; then dx) and the operand pairs of every weight gradient (hmid, n2, dg, du, p, dy1; s, dx1, n) for
  * hmx_linear_wgrad_batch_f32, plus per-wave partials of the two RMSNorm scale gradients, shaped
- * (hmx_block_scale_partial_rows(T), d) (sum with hmx_colsum_f32).
+ * (hmx_block_scale_partial_rows(T), d) (sum with hmx_colsum_f32; a launch writes every row of that buffer -- the
+ * rows beyond its waves as zeros -- so the buffer need not be cleared).
  * One argument block serves the four calls; each reads the fields its half needs.
  * Widened blocks.  A width whose head_dim is not a multiple of 32 -- the reference's default hidden size 60 gives
  * head_dim 30 (main.py:54, :57) -- runs on the same kernels in a widened layout: every head's head_dim features are
