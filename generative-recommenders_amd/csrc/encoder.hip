@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, KS <= 4 ? 4 : 2) void linear_kernel(LinearPara
     }
 }
 
-// ---------------------------------------------------------------------------- weight gradient (fp32 MFMA)
+// ---------------------------------------------------------------------------- weight gradient (split-bf16 or fp32 MFMA)
 // dW[n][k] (+)= sum_t dY[t][n] * X[t][k] * in_rowmask[t];  dbias[n] (+)= sum_t dY[t][n].
 // One weight-gradient product of a batched launch.
 struct WgradJob {
@@ -485,6 +485,7 @@ struct WgradParams {
     int n_jobs;
     float* part;             // slabs [job][macro tile][group][tn * tk tile images of 16 x 64, 128 bias sums]
     unsigned* tickets;       // one arrival counter per global macro tile, zero on entry and on exit
+    int fp32_mfma;           // 1: products on the fp32 MFMA; 0: operands split into two bf16 numbers, bf16 MFMA
 };
 
 // Arrival counters of the in-launch reduction below: one word per macro tile of a launch, in a slot chosen by the
@@ -521,7 +522,7 @@ struct WgradShared {
 // load each: accumulator tile (a, b) row i is output row n0 + TN i + a, column i is k0 + TK i + b.  Every operand
 // element is read once per macro tile instead of once per 32 x 32 tile, which is what bounds this kernel: the operands
 // of a launch do not fit L2, so each re-read comes from HBM.  The bias sum rides on the dY values in the vector unit.
-template <int TN, int TK>
+template <int TN, int TK, bool BF16>
 __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const WgradJob& jb, int gtile, WgradShared& sh) {
     constexpr int kSteps = TN * TK >= 8 ? 4 : 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -532,7 +533,7 @@ __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const Wgr
     const bool n_ok = n < jb.N, k_ok = k < jb.K;       // N % TN == 0 and K % TK == 0: a lane's vector is all in or all out
     const int n_groups = gridDim.x;
     int64_t tps = hmx_ceil_div(jb.T, (int64_t)n_groups * 4);
-    tps += tps & 1;
+    tps = BF16 ? (tps + 15) / 16 * 16 : tps + (tps & 1);
     const int64_t t0 = min(jb.T, ((int64_t)blockIdx.x * 4 + wave) * tps);
     const int64_t t1 = min(jb.T, t0 + tps);
     f32x16 acc[TN][TK];
@@ -549,74 +550,147 @@ __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const Wgr
     const float* bp = jb.X + (k_ok ? k : 0);
     const float* mp = jb.in_rowmask;
     const int64_t ldy = jb.ldy, ldx = jb.ldx;
-    auto load_trip = [&](float(&av)[kSteps][TN], float(&bv)[kSteps][TK], int64_t t) {   // tokens t .. t + 2 kSteps - 1 < t1
+    if constexpr (BF16) {
+        // Split-bf16 form: a trip is sixteen tokens = ONE 32 x 32 x 16 MFMA per product term.  Lane (i, h) reads, for its
+        // eight tokens t + 8 h + e, the same TN / TK consecutive columns as above (one vector load per token and
+        // operand: the same requests as the fp32 form), writes each column's eight values as a sum of two bf16
+        // numbers (hi + lo, 16 significant bits) and the accumulator receives hi*lo + lo*hi + hi*hi: the multiply rate
+        // is 5 x that of the fp32 MFMA, which leaves the operand reads as the bound.  The raw rows of the next trip
+        // are in flight while this trip's fragments are multiplied.
+        float ra[8][TN], rb[8][TK];
+        auto load16 = [&](int64_t t) {              // tokens t .. t + 15, rows past t1 - 1 replaced by row t (dropped below)
 #pragma unroll
-        for (int u = 0; u < kSteps; ++u) {
-            const int64_t tt = t + 2 * u + h;
-            wgrad_load<TN>(av[u], ap + tt * ldy);
-            wgrad_load<TK>(bv[u], bp + tt * ldx);
+            for (int e = 0; e < 8; ++e) {
+                const int64_t tt = t + 8 * h + e;
+                const int64_t tc = tt < t1 ? tt : t;
+                wgrad_load<TN>(ra[e], ap + tc * ldy);
+                wgrad_load<TK>(rb[e], bp + tc * ldx);
+            }
+        };
+        auto split8 = [&](const float(&v)[8], short8& hi, short8& lo) {
+            uint32_t hw[4], lw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hw[e] = hmx_pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                lw[e] = hmx_pack_bf16x2(v[2 * e] - __uint_as_float(hw[e] << 16), v[2 * e + 1] - __uint_as_float(hw[e] & 0xffff0000u));
+            }
+            hi = __builtin_bit_cast(short8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+            lo = __builtin_bit_cast(short8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+        };
+        if (t0 < t1) load16(t0);
+        for (int64_t t = t0; t < t1; t += 16) {
+            short8 ah[TN], al[TN], bh[TK], bl[TK];
+            float m[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t tt = t + 8 * h + e;
+                m[e] = tt < t1 ? 1.f : 0.f;
+            }
+            if (mp != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int64_t tt = t + 8 * h + e;
+                    if (tt < t1) m[e] = mp[tt];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int64_t tt = t + 8 * h + e;
+                    v[e] = (n_ok && tt < t1) ? ra[e][a] : 0.f;
+                    bsum[a] += v[e];
+                }
+                split8(v, ah[a], al[a]);
+            }
+#pragma unroll
+            for (int b = 0; b < TK; ++b) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = k_ok ? rb[e][b] * m[e] : 0.f;
+                split8(v, bh[b], bl[b]);
+            }
+            if (t + 16 < t1) load16(t + 16);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TK; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                }
         }
-        if (mp != nullptr) {
-#pragma unroll
+    } else {
+        auto load_trip = [&](float(&av)[kSteps][TN], float(&bv)[kSteps][TK], int64_t t) {   // tokens t .. t + 2 kSteps - 1 < t1
+    #pragma unroll
             for (int u = 0; u < kSteps; ++u) {
-                const float m = mp[t + 2 * u + h];
-#pragma unroll
-                for (int b = 0; b < TK; ++b) bv[u][b] *= m;
+                const int64_t tt = t + 2 * u + h;
+                wgrad_load<TN>(av[u], ap + tt * ldy);
+                wgrad_load<TK>(bv[u], bp + tt * ldx);
+            }
+            if (mp != nullptr) {
+    #pragma unroll
+                for (int u = 0; u < kSteps; ++u) {
+                    const float m = mp[t + 2 * u + h];
+    #pragma unroll
+                    for (int b = 0; b < TK; ++b) bv[u][b] *= m;
+                }
+            }
+        };
+        auto mfma_step = [&](const float(&av)[TN], const float(&bv)[TK]) {
+            float az[TN], bz[TK];
+    #pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                az[a] = n_ok ? av[a] : 0.f;
+                bsum[a] += az[a];
+            }
+    #pragma unroll
+            for (int b = 0; b < TK; ++b) bz[b] = k_ok ? bv[b] : 0.f;
+    #pragma unroll
+            for (int a = 0; a < TN; ++a)
+    #pragma unroll
+                for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[a], bz[b], acc[a][b], 0, 0, 0);
+        };
+        auto mfma_trip = [&](const float(&av)[kSteps][TN], const float(&bv)[kSteps][TK]) {
+    #pragma unroll
+            for (int u = 0; u < kSteps; ++u) mfma_step(av[u], bv[u]);
+        };
+        // Trips of kSteps steps through a ring of kRing operand buffers: the loads of trip j + kRing - 1 are issued before
+        // the MFMAs of trip j, so two further trips are in flight while one is consumed (HBM latency under load is several
+        // trips long).  The ring index is static: the loop body is kRing stages.  Loads past the last trip repeat the last
+        // trip (in bounds, never consumed).
+        constexpr int kRing = 3;
+        const int64_t n_trips = (t1 - t0) / (2 * kSteps);
+        if (n_trips > 0) {
+            float av[kRing][kSteps][TN], bv[kRing][kSteps][TK];
+            const int64_t last = n_trips - 1;
+    #pragma unroll
+            for (int s = 0; s < kRing - 1; ++s) load_trip(av[s], bv[s], t0 + min((int64_t)s, last) * (2 * kSteps));
+            for (int64_t trip = 0; trip < n_trips; trip += kRing) {
+    #pragma unroll
+                for (int s = 0; s < kRing; ++s) {
+                    load_trip(av[(s + kRing - 1) % kRing], bv[(s + kRing - 1) % kRing],
+                              t0 + min(trip + s + kRing - 1, last) * (2 * kSteps));
+                    if (trip + s < n_trips) mfma_trip(av[s], bv[s]);
+                }
             }
         }
-    };
-    auto mfma_step = [&](const float(&av)[TN], const float(&bv)[TK]) {
-        float az[TN], bz[TK];
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            az[a] = n_ok ? av[a] : 0.f;
-            bsum[a] += az[a];
+        int64_t t = t0 + n_trips * (2 * kSteps);
+        for (; t < t1; t += 2) {                        // the split's last tokens, one step at a time
+            const int64_t tt = t + h;
+            const bool ok = tt < t1;
+            const int64_t tc = ok ? tt : t;             // t < t1: a valid row
+            float av[TN], bv[TK];
+            wgrad_load<TN>(av, ap + tc * ldy);
+            wgrad_load<TK>(bv, bp + tc * ldx);
+            const float m = ok ? (mp ? mp[tc] : 1.f) : 0.f;
+    #pragma unroll
+            for (int a = 0; a < TN; ++a) av[a] = ok ? av[a] : 0.f;
+    #pragma unroll
+            for (int b = 0; b < TK; ++b) bv[b] *= m;
+            mfma_step(av, bv);
         }
-#pragma unroll
-        for (int b = 0; b < TK; ++b) bz[b] = k_ok ? bv[b] : 0.f;
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int b = 0; b < TK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[a], bz[b], acc[a][b], 0, 0, 0);
-    };
-    auto mfma_trip = [&](const float(&av)[kSteps][TN], const float(&bv)[kSteps][TK]) {
-#pragma unroll
-        for (int u = 0; u < kSteps; ++u) mfma_step(av[u], bv[u]);
-    };
-    // Trips of kSteps steps through a ring of kRing operand buffers: the loads of trip j + kRing - 1 are issued before
-    // the MFMAs of trip j, so two further trips are in flight while one is consumed (HBM latency under load is several
-    // trips long).  The ring index is static: the loop body is kRing stages.  Loads past the last trip repeat the last
-    // trip (in bounds, never consumed).
-    constexpr int kRing = 3;
-    const int64_t n_trips = (t1 - t0) / (2 * kSteps);
-    if (n_trips > 0) {
-        float av[kRing][kSteps][TN], bv[kRing][kSteps][TK];
-        const int64_t last = n_trips - 1;
-#pragma unroll
-        for (int s = 0; s < kRing - 1; ++s) load_trip(av[s], bv[s], t0 + min((int64_t)s, last) * (2 * kSteps));
-        for (int64_t trip = 0; trip < n_trips; trip += kRing) {
-#pragma unroll
-            for (int s = 0; s < kRing; ++s) {
-                load_trip(av[(s + kRing - 1) % kRing], bv[(s + kRing - 1) % kRing],
-                          t0 + min(trip + s + kRing - 1, last) * (2 * kSteps));
-                if (trip + s < n_trips) mfma_trip(av[s], bv[s]);
-            }
-        }
-    }
-    int64_t t = t0 + n_trips * (2 * kSteps);
-    for (; t < t1; t += 2) {                        // the split's last tokens, one step at a time
-        const int64_t tt = t + h;
-        const bool ok = tt < t1;
-        const int64_t tc = ok ? tt : t;             // t < t1: a valid row
-        float av[TN], bv[TK];
-        wgrad_load<TN>(av, ap + tc * ldy);
-        wgrad_load<TK>(bv, bp + tc * ldx);
-        const float m = ok ? (mp ? mp[tc] : 1.f) : 0.f;
-#pragma unroll
-        for (int a = 0; a < TN; ++a) av[a] = ok ? av[a] : 0.f;
-#pragma unroll
-        for (int b = 0; b < TK; ++b) bv[b] *= m;
-        mfma_step(av, bv);
     }
     // Output of element e = r * 64 + lane_e of tile image (a, b)
     auto finish = [&](const float4& tot, int a, int b) {
@@ -733,6 +807,20 @@ __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const Wgr
     }
 }
 
+template <bool BF16>
+__device__ __forceinline__ void wgrad_dispatch(const WgradParams& p, const WgradJob& jb, int gtile, WgradShared& sh) {
+    switch (jb.tn * 8 + jb.tk) {
+        case 4 * 8 + 2: wgrad_macro_tile<4, 2, BF16>(p, jb, gtile, sh); break;
+        case 2 * 8 + 4: wgrad_macro_tile<2, 4, BF16>(p, jb, gtile, sh); break;
+        case 4 * 8 + 1: wgrad_macro_tile<4, 1, BF16>(p, jb, gtile, sh); break;
+        case 1 * 8 + 4: wgrad_macro_tile<1, 4, BF16>(p, jb, gtile, sh); break;
+        case 2 * 8 + 2: wgrad_macro_tile<2, 2, BF16>(p, jb, gtile, sh); break;
+        case 2 * 8 + 1: wgrad_macro_tile<2, 1, BF16>(p, jb, gtile, sh); break;
+        case 1 * 8 + 2: wgrad_macro_tile<1, 2, BF16>(p, jb, gtile, sh); break;
+        default: wgrad_macro_tile<1, 1, BF16>(p, jb, gtile, sh); break;
+    }
+}
+
 // Weight gradients of up to kWgradMaxJobs projections in one launch.  blockIdx.y walks the macro tiles of all jobs,
 // blockIdx.x the token-split groups.  One workgroup = four waves = four consecutive token splits of ONE macro tile.  A
 // wave runs trips of MFMA steps (2 tokens each) with the loads of the next trip issued before the MFMAs of this one.
@@ -744,17 +832,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     const int gtile = blockIdx.y;
     int ji = 0;
     while (ji + 1 < p.n_jobs && p.job[ji + 1].tile0 <= gtile) ++ji;     // wave-uniform scan of at most 24 entries
-    const WgradJob& jb = p.job[ji];
-    switch (jb.tn * 8 + jb.tk) {
-        case 4 * 8 + 2: wgrad_macro_tile<4, 2>(p, jb, gtile, sh); break;
-        case 2 * 8 + 4: wgrad_macro_tile<2, 4>(p, jb, gtile, sh); break;
-        case 4 * 8 + 1: wgrad_macro_tile<4, 1>(p, jb, gtile, sh); break;
-        case 1 * 8 + 4: wgrad_macro_tile<1, 4>(p, jb, gtile, sh); break;
-        case 2 * 8 + 2: wgrad_macro_tile<2, 2>(p, jb, gtile, sh); break;
-        case 2 * 8 + 1: wgrad_macro_tile<2, 1>(p, jb, gtile, sh); break;
-        case 1 * 8 + 2: wgrad_macro_tile<1, 2>(p, jb, gtile, sh); break;
-        default: wgrad_macro_tile<1, 1>(p, jb, gtile, sh); break;
-    }
+    const WgradJob jb = p.job[ji];      // a copy in scalar registers (through a reference the argument block went to scratch)
+    if (p.fp32_mfma) wgrad_dispatch<false>(p, jb, gtile, sh);
+    else wgrad_dispatch<true>(p, jb, gtile, sh);
 }
 
 // ---------------------------------------------------------------------------- pointwise kernels
@@ -1565,6 +1645,13 @@ static WgradPlan wgrad_plan(const hmx_wgrad_desc* descs, int64_t n) {
     return pl;
 }
 
+static int g_wgrad_fp32 = 0;     // 0: split-bf16 operands on the bf16 MFMA (fp32-class accuracy); 1: fp32 MFMA
+
+extern "C" int hmx_set_wgrad_precision(int fp32_mfma) {
+    g_wgrad_fp32 = fp32_mfma != 0;
+    return HMX_OK;
+}
+
 extern "C" size_t hmx_linear_wgrad_batch_workspace_bytes(const hmx_wgrad_desc* descs, int64_t n) {
     if (!descs || n <= 0) return 256;
     const WgradPlan pl = wgrad_plan(descs, n);
@@ -1602,6 +1689,7 @@ extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n
     }
     if (nj == 0) return HMX_OK;
     p.n_jobs = nj;
+    p.fp32_mfma = g_wgrad_fp32;
     p.part = static_cast<float*>(workspace);
     const int rc = wgrad_tickets_for_call((hipStream_t)stream, &p.tickets);
     if (rc != HMX_OK) return rc;

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "hmx_colsum_workspace_bytes": (c_size_t, [I64, I64]),
     "hmx_colsum_f32": (c_int, [P, I64, I64, I64, P, P, c_size_t, P]),
     "hmx_set_linear_precision": (c_int, [c_int]),
+    "hmx_set_wgrad_precision": (c_int, [c_int]),
     "hmx_linear_f32": (c_int, [P, I64, P, I64, I64, P, I64, I64, I64, P, I64, P, I64, F, P, I64, F, P, P, c_int, P]),
     "hmx_heads_linear_f32": (c_int, [P, I64, I64, P, I64, I64, I64, I64, I64, P, I64, I64, c_int, c_int, P]),
     "hmx_linear_wgrad_workspace_bytes": (c_size_t, [I64, I64, I64]),
@@ -217,3 +218,9 @@ def set_linear_precision(split_bf16=True):
     global SPLIT_BF16
     check(lib().hmx_set_linear_precision(1 if split_bf16 else 0), "hmx_set_linear_precision")
     SPLIT_BF16 = bool(split_bf16)
+
+
+def set_wgrad_precision(fp32_mfma=False):
+    """False (default): weight gradients multiply split-bf16 operands on the bf16 MFMA (fp32-class accuracy);
+    True: on the fp32 MFMA."""
+    check(lib().hmx_set_wgrad_precision(1 if fp32_mfma else 0), "hmx_set_wgrad_precision")

@@ -304,8 +304,11 @@ int hmx_heads_linear_f32(const float* X, int64_t ldx, int64_t x_head_stride, con
                          int64_t w_cs, int64_t T, int64_t N, int64_t K, float* Y, int64_t ldy, int64_t y_head_stride,
                          int n_heads, int accumulate, void* stream);
 
-/* Weight / bias gradient on fp32 MFMA: dW[n * ldw + k] = sum_t dY[t, n] * X[t, k] * in_rowmask[t],
- * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  A wave owns up to eight 32 x 32 output tiles and reads its operands
+/* Weight / bias gradient (the dW / db of every nn.Linear above): dW[n * ldw + k] = sum_t dY[t, n] * X[t, k] * in_rowmask[t],
+ * dbias[n] = sum_t dY[t, n] (dbias may be NULL).  Precision (process-wide, hmx_set_wgrad_precision): fp32_mfma = 0
+ * (default) writes every operand as a sum of two bf16 numbers and accumulates hi*lo + lo*hi + hi*hi on the bf16 MFMA in
+ * fp32 (16 significant bits per operand, as hmx_linear_f32 does); fp32_mfma = 1 multiplies on the fp32 MFMA (5 x
+ * slower multiply rate).  The bias sum is fp32 either way.  A wave owns up to eight 32 x 32 output tiles and reads its operands
  * with vector loads where base, row stride and extent allow (16-byte aligned dY / X with ldy, ldx, N, K multiples of
  * four give the widest tiles; anything else still works, with more re-reads of the operands).
  * One launch: token splits write partial tiles to the workspace and
@@ -330,6 +333,7 @@ typedef struct hmx_wgrad_desc {
      * block address the true weight: N, K, ldy, ldx describe the widened operands, dW / ldw / dbias the true ones. */
     int32_t n_group, n_group_padded, k_group, k_group_padded;
 } hmx_wgrad_desc;
+int hmx_set_wgrad_precision(int fp32_mfma);
 size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t K);
 int hmx_linear_wgrad_f32(const float* dY, int64_t ldy, const float* X, int64_t ldx, const float* in_rowmask, int64_t T,
                          int64_t N, int64_t K, float* dW, int64_t ldw, float* dbias, void* workspace,
