@@ -807,11 +807,11 @@ __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const Wgr
     }
 }
 
-template <bool BF16>
+template <bool BF16, bool SMALL>
 __device__ __forceinline__ void wgrad_dispatch(const WgradParams& p, const WgradJob& jb, int gtile, WgradShared& sh) {
     switch (jb.tn * 8 + jb.tk) {
-        case 4 * 8 + 2: wgrad_macro_tile<4, 2, BF16>(p, jb, gtile, sh); break;
-        case 2 * 8 + 4: wgrad_macro_tile<2, 4, BF16>(p, jb, gtile, sh); break;
+        case 4 * 8 + 2: if constexpr (!SMALL) wgrad_macro_tile<4, 2, BF16>(p, jb, gtile, sh); break;
+        case 2 * 8 + 4: if constexpr (!SMALL) wgrad_macro_tile<2, 4, BF16>(p, jb, gtile, sh); break;
         case 4 * 8 + 1: wgrad_macro_tile<4, 1, BF16>(p, jb, gtile, sh); break;
         case 1 * 8 + 4: wgrad_macro_tile<1, 4, BF16>(p, jb, gtile, sh); break;
         case 2 * 8 + 2: wgrad_macro_tile<2, 2, BF16>(p, jb, gtile, sh); break;
@@ -823,18 +823,25 @@ __device__ __forceinline__ void wgrad_dispatch(const WgradParams& p, const Wgrad
 
 // Weight gradients of up to kWgradMaxJobs projections in one launch.  blockIdx.y walks the macro tiles of all jobs,
 // blockIdx.x the token-split groups.  One workgroup = four waves = four consecutive token splits of ONE macro tile.  A
-// wave runs trips of MFMA steps (2 tokens each) with the loads of the next trip issued before the MFMAs of this one.
+// wave runs trips of MFMA steps with the loads of the next trip issued before the MFMAs of this one.
 // The four partial results are added in LDS (wave order) and written as one slab; the workgroup that arrives last at
 // the tile's counter adds the slabs in group order and writes (or adds to) dW / dbias: fixed association order, no
 // float atomics, no second launch.
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
+// SMALL: every job of the launch has at most four accumulator tiles per wave; the kernel is then built for three
+// workgroups per CU instead of two (the operand reads in flight per CU are what bounds it).
+template <bool SMALL>
+__global__ __launch_bounds__(256, SMALL ? 3 : 2) void wgrad_kernel(WgradParams p) {
     __shared__ WgradShared sh;
     const int gtile = blockIdx.y;
     int ji = 0;
     while (ji + 1 < p.n_jobs && p.job[ji + 1].tile0 <= gtile) ++ji;     // wave-uniform scan of at most 24 entries
     const WgradJob jb = p.job[ji];      // a copy in scalar registers (through a reference the argument block went to scratch)
-    if (p.fp32_mfma) wgrad_dispatch<false>(p, jb, gtile, sh);
-    else wgrad_dispatch<true>(p, jb, gtile, sh);
+    if constexpr (SMALL) {
+        wgrad_dispatch<true, true>(p, jb, gtile, sh);          // the host launches this form for the bf16 MFMA only
+    } else {
+        if (p.fp32_mfma) wgrad_dispatch<false, false>(p, jb, gtile, sh);
+        else wgrad_dispatch<true, false>(p, jb, gtile, sh);
+    }
 }
 
 // ---------------------------------------------------------------------------- pointwise kernels
@@ -1551,15 +1558,17 @@ extern "C" int hmx_heads_linear_f32(const float* X, int64_t ldx, int64_t x_head_
 // runs 512 at a time, and the workgroups of a launch take about equally long: a grid of 528 would run as two rounds
 // of which the second is nearly empty.  Hence as many groups as keep groups x tiles within ONE round (launches with
 // more tiles than that run in several rounds of one group), at least 64 tokens per wave.
-constexpr int64_t kWgradResident = 512;
-static int64_t wgrad_groups(int64_t T_max, int64_t tiles) {
-    int64_t g = std::max<int64_t>(1, kWgradResident / std::max<int64_t>(tiles, 1));
+constexpr int64_t kWgradResident = 512, kWgradResidentSmall = 768;      // two / three workgroups per CU
+static int64_t wgrad_groups(int64_t T_max, int64_t tiles, bool small = false) {
+    int64_t g = std::max<int64_t>(1, (small ? kWgradResidentSmall : kWgradResident) / std::max<int64_t>(tiles, 1));
     g = std::min<int64_t>(g, hmx_ceil_div(T_max, 4 * 64));
     return std::max<int64_t>(1, std::min<int64_t>(g, 128));
 }
 
+static int g_wgrad_fp32 = 0;     // 0: split-bf16 operands on the bf16 MFMA (fp32-class accuracy); 1: fp32 MFMA
+
 // Macro tile of a product: as many 32-wide tiles along N and K as vector loads allow (a lane reads tn consecutive
-// columns of dY and tk of X, so base, row stride and extent must be multiples of the vector), eight accumulators at most.
+// columns of dY and tk of X, so base, row stride and extent must be multiples of the vector).
 struct WgradShape {
     int tn, tk;
     int64_t tiles;
@@ -1572,7 +1581,11 @@ static WgradShape wgrad_shape(const hmx_wgrad_desc& d) {
         return 1;
     };
     WgradShape s{width(d.dY, d.ldy, d.N), width(d.X, d.ldx, d.K), 0};
-    while (s.tn * s.tk > 8) {
+    // accumulator tiles per wave: eight on the fp32 MFMA (its multiply rate is the bound: fewest operand re-reads),
+    // four on the bf16 MFMA (bound by the reads in flight: smaller tiles leave registers for them; measured
+    // 1.34 -> 1.11 ms per configs[1] step)
+    const int cap = g_wgrad_fp32 ? 8 : 4;
+    while (s.tn * s.tk > cap) {
         if (s.tk >= s.tn) s.tk /= 2;
         else s.tn /= 2;
     }
@@ -1632,6 +1645,7 @@ static int wgrad_tickets_for_call(hipStream_t stream, unsigned** out) {
 // Walks the descriptors of a batch: macro tiles and slab floats (per token-split group) of the whole launch.
 struct WgradPlan {
     int64_t tiles = 0, slab_floats = 0, t_max = 1;
+    bool small = true;       // no job with more than four accumulator tiles per wave
 };
 static WgradPlan wgrad_plan(const hmx_wgrad_desc* descs, int64_t n) {
     WgradPlan pl;
@@ -1641,11 +1655,14 @@ static WgradPlan wgrad_plan(const hmx_wgrad_desc* descs, int64_t n) {
         pl.tiles += sh.tiles;
         pl.slab_floats += sh.tiles * wgrad_slab_floats(sh.tn, sh.tk);
         pl.t_max = std::max<int64_t>(pl.t_max, descs[j].T);
+        pl.small = pl.small && sh.tn * sh.tk <= 4;
     }
+    // three workgroups per CU pay when a wave has many trips to run (configs[4]: 5.9 -> 4.85 ms); with few, the longer
+    // chain of slabs the last workgroup of a tile adds costs more than the extra waves bring (configs[1]: 1.11 -> 1.42 ms)
+    pl.small = pl.small && !g_wgrad_fp32 && pl.tiles > 0 &&
+               pl.t_max / (4 * wgrad_groups(pl.t_max, pl.tiles, true)) >= 2048;
     return pl;
 }
-
-static int g_wgrad_fp32 = 0;     // 0: split-bf16 operands on the bf16 MFMA (fp32-class accuracy); 1: fp32 MFMA
 
 extern "C" int hmx_set_wgrad_precision(int fp32_mfma) {
     g_wgrad_fp32 = fp32_mfma != 0;
@@ -1656,7 +1673,7 @@ extern "C" size_t hmx_linear_wgrad_batch_workspace_bytes(const hmx_wgrad_desc* d
     if (!descs || n <= 0) return 256;
     const WgradPlan pl = wgrad_plan(descs, n);
     if (pl.tiles == 0) return 256;
-    return (size_t)(wgrad_groups(pl.t_max, pl.tiles) * pl.slab_floats) * sizeof(float) + 256;
+    return (size_t)(wgrad_groups(pl.t_max, pl.tiles, pl.small) * pl.slab_floats) * sizeof(float) + 256;
 }
 
 extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n, void* workspace, size_t workspace_bytes,
@@ -1667,7 +1684,7 @@ extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n
     if (workspace_bytes < hmx_linear_wgrad_batch_workspace_bytes(descs, n)) return HMX_EWORKSPACE;
     const WgradPlan pl = wgrad_plan(descs, n);
     if (pl.tiles > kWgradMaxTiles) return HMX_EINVAL;
-    const int64_t G = wgrad_groups(pl.t_max, std::max<int64_t>(pl.tiles, 1));
+    const int64_t G = wgrad_groups(pl.t_max, std::max<int64_t>(pl.tiles, 1), pl.small);
     WgradParams p{};
     int64_t tiles = 0, slab0 = 0;
     int nj = 0;
@@ -1694,7 +1711,8 @@ extern "C" int hmx_linear_wgrad_batch_f32(const hmx_wgrad_desc* descs, int64_t n
     const int rc = wgrad_tickets_for_call((hipStream_t)stream, &p.tickets);
     if (rc != HMX_OK) return rc;
     void* span = hmx_profile_begin("proj", (hipStream_t)stream);
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)G, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
+    if (pl.small) hipLaunchKernelGGL(wgrad_kernel<true>, dim3((unsigned)G, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_kernel<false>, dim3((unsigned)G, (unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
     hmx_profile_end(span, (hipStream_t)stream);
     HMX_CHECK_LAUNCH();
     return HMX_OK;
@@ -1706,7 +1724,7 @@ extern "C" size_t hmx_linear_wgrad_workspace_bytes(int64_t T, int64_t N, int64_t
     for (int tn = 1; tn <= 4; tn *= 2)
         for (int tk = 1; tk * tn <= 8 && tk <= 4; tk *= 2) {
             const int64_t tiles = hmx_ceil_div(N, 32 * tn) * hmx_ceil_div(K, 32 * tk);
-            floats = std::max<int64_t>(floats, wgrad_groups(T, tiles) * tiles * wgrad_slab_floats(tn, tk));
+            floats = std::max<int64_t>(floats, wgrad_groups(T, tiles, tn * tk <= 4 && !g_wgrad_fp32) * tiles * wgrad_slab_floats(tn, tk));
         }
     return (size_t)floats * sizeof(float) + 256;
 }
