@@ -522,8 +522,9 @@ struct WgradShared {
 // load each: accumulator tile (a, b) row i is output row n0 + TN i + a, column i is k0 + TK i + b.  Every operand
 // element is read once per macro tile instead of once per 32 x 32 tile, which is what bounds this kernel: the operands
 // of a launch do not fit L2, so each re-read comes from HBM.  The bias sum rides on the dY values in the vector unit.
-template <int TN, int TK, bool BF16>
+template <int TN, int TK, bool BF16, int AHEAD>
 __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const WgradJob& jb, int gtile, WgradShared& sh) {
+    if constexpr (BF16 && TN * TK > 4) return;       // the host gives the bf16 form at most four tiles per wave
     constexpr int kSteps = TN * TK >= 8 ? 4 : 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const int mtile = gtile - jb.tile0;
@@ -557,14 +558,17 @@ __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const Wgr
         // numbers (hi + lo, 16 significant bits) and the accumulator receives hi*lo + lo*hi + hi*hi: the multiply rate
         // is 5 x that of the fp32 MFMA, which leaves the operand reads as the bound.  The raw rows of the next trip
         // are in flight while this trip's fragments are multiplied.
-        float ra[8][TN], rb[8][TK];
-        auto load16 = [&](int64_t t) {              // tokens t .. t + 15, rows past t1 - 1 replaced by row t (dropped below)
+        // AHEAD trips of raw rows (and their mask values) are in flight
+        constexpr bool kMaskAhead = AHEAD > 1;       // the mask values travel with the rows where registers allow
+        float ra[AHEAD][8][TN], rb[AHEAD][8][TK], rm[kMaskAhead ? AHEAD : 1][8];
+        auto load16 = [&](int s, int64_t t) {       // tokens t .. t + 15, rows past t1 - 1 replaced by row t (dropped below)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int64_t tt = t + 8 * h + e;
                 const int64_t tc = tt < t1 ? tt : t;
-                wgrad_load<TN>(ra[e], ap + tc * ldy);
-                wgrad_load<TK>(rb[e], bp + tc * ldx);
+                wgrad_load<TN>(ra[s][e], ap + tc * ldy);
+                wgrad_load<TK>(rb[s][e], bp + tc * ldx);
+                if constexpr (kMaskAhead) rm[s][e] = mp != nullptr ? mp[tc] : 1.f;
             }
         };
         auto split8 = [&](const float(&v)[8], short8& hi, short8& lo) {
@@ -577,49 +581,51 @@ __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const Wgr
             hi = __builtin_bit_cast(short8, make_uint4(hw[0], hw[1], hw[2], hw[3]));
             lo = __builtin_bit_cast(short8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
         };
-        if (t0 < t1) load16(t0);
-        for (int64_t t = t0; t < t1; t += 16) {
-            short8 ah[TN], al[TN], bh[TK], bl[TK];
-            float m[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int64_t tt = t + 8 * h + e;
-                m[e] = tt < t1 ? 1.f : 0.f;
-            }
-            if (mp != nullptr) {
+        for (int s = 0; s < AHEAD; ++s)
+            if (t0 + 16 * s < t1) load16(s, t0 + 16 * s);
+        for (int64_t tb = t0; tb < t1; tb += 16 * AHEAD) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int64_t tt = t + 8 * h + e;
-                    if (tt < t1) m[e] = mp[tt];
+            for (int s = 0; s < AHEAD; ++s) {
+                const int64_t t = tb + 16 * s;
+                if (t >= t1) break;                 // wave-uniform
+                short8 ah[TN], al[TN], bh[TK], bl[TK];
+                const bool whole = t + 16 <= t1;
+                if constexpr (!kMaskAhead) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int64_t tt = t + 8 * h + e;
+                        rm[0][e] = (mp != nullptr && tt < t1) ? mp[tt] : 1.f;
+                    }
                 }
-            }
 #pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                float v[8];
+                for (int a = 0; a < TN; ++a) {
+                    float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int64_t tt = t + 8 * h + e;
-                    v[e] = (n_ok && tt < t1) ? ra[e][a] : 0.f;
-                    bsum[a] += v[e];
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = (n_ok && (whole || t + 8 * h + e < t1)) ? ra[s][e][a] : 0.f;
+                        bsum[a] += v[e];
+                    }
+                    split8(v, ah[a], al[a]);
                 }
-                split8(v, ah[a], al[a]);
-            }
-#pragma unroll
-            for (int b = 0; b < TK; ++b) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = k_ok ? rb[e][b] * m[e] : 0.f;
-                split8(v, bh[b], bl[b]);
-            }
-            if (t + 16 < t1) load16(t + 16);
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
 #pragma unroll
                 for (int b = 0; b < TK; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[e] = (k_ok && (whole || t + 8 * h + e < t1)) ? rb[s][e][b] * rm[kMaskAhead ? s : 0][e] : 0.f;
+                    split8(v, bh[b], bl[b]);
                 }
+                if (t + 16 * AHEAD < t1) load16(s, t + 16 * AHEAD);
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TK; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+            }
         }
     } else {
         auto load_trip = [&](float(&av)[kSteps][TN], float(&bv)[kSteps][TK], int64_t t) {   // tokens t .. t + 2 kSteps - 1 < t1
@@ -780,25 +786,32 @@ __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const Wgr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    // last to arrive: the slabs of every group, added in group order
-#pragma unroll 1
-    for (int ab = 0; ab < TN * TK; ++ab) {
-        const float4* src = reinterpret_cast<const float4*>(slabs) + ab * 256 + threadIdx.x;
+    // last to arrive: the slabs of every group, added in group order; eight groups of up to four of the macro tile's
+    // images are requested together (32 reads in flight per lane: the chain of round trips is the tail of the launch)
+    constexpr int kImgs = TN * TK < 4 ? TN * TK : 4;
+#pragma unroll
+    for (int ab0 = 0; ab0 < TN * TK; ab0 += kImgs) {
+        const float4* src = reinterpret_cast<const float4*>(slabs) + ab0 * 256 + threadIdx.x;
         const int64_t stride = slab_f / 4;
-        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-        int g = 0;
-        for (; g + 8 <= n_groups; g += 8) {          // eight slabs requested together
-            float4 o[8];
+        float4 tot[kImgs];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) o[u] = src[(int64_t)(g + u) * stride];
+        for (int ab = 0; ab < kImgs; ++ab) tot[ab] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < n_groups; g += 8) {
+            float4 o[kImgs][8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { tot.x += o[u].x; tot.y += o[u].y; tot.z += o[u].z; tot.w += o[u].w; }
+            for (int ab = 0; ab < kImgs; ++ab)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    o[ab][u] = g + u < n_groups ? src[(int64_t)(g + u) * stride + ab * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ab = 0; ab < kImgs; ++ab)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    tot[ab].x += o[ab][u].x; tot[ab].y += o[ab][u].y; tot[ab].z += o[ab][u].z; tot[ab].w += o[ab][u].w;
+                }
         }
-        for (; g < n_groups; ++g) {
-            const float4 o = src[(int64_t)g * stride];
-            tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
-        }
-        finish(tot, ab / TK, ab % TK);
+#pragma unroll
+        for (int ab = 0; ab < kImgs; ++ab) finish(tot[ab], (ab0 + ab) / TK, (ab0 + ab) % TK);
     }
     if (bias_here && threadIdx.x < 32 * TN) {
         float tot = 0.f;
@@ -810,14 +823,14 @@ __device__ __forceinline__ void wgrad_macro_tile(const WgradParams& p, const Wgr
 template <bool BF16, bool SMALL>
 __device__ __forceinline__ void wgrad_dispatch(const WgradParams& p, const WgradJob& jb, int gtile, WgradShared& sh) {
     switch (jb.tn * 8 + jb.tk) {
-        case 4 * 8 + 2: if constexpr (!SMALL) wgrad_macro_tile<4, 2, BF16>(p, jb, gtile, sh); break;
-        case 2 * 8 + 4: if constexpr (!SMALL) wgrad_macro_tile<2, 4, BF16>(p, jb, gtile, sh); break;
-        case 4 * 8 + 1: wgrad_macro_tile<4, 1, BF16>(p, jb, gtile, sh); break;
-        case 1 * 8 + 4: wgrad_macro_tile<1, 4, BF16>(p, jb, gtile, sh); break;
-        case 2 * 8 + 2: wgrad_macro_tile<2, 2, BF16>(p, jb, gtile, sh); break;
-        case 2 * 8 + 1: wgrad_macro_tile<2, 1, BF16>(p, jb, gtile, sh); break;
-        case 1 * 8 + 2: wgrad_macro_tile<1, 2, BF16>(p, jb, gtile, sh); break;
-        default: wgrad_macro_tile<1, 1, BF16>(p, jb, gtile, sh); break;
+        case 4 * 8 + 2: if constexpr (!SMALL) wgrad_macro_tile<4, 2, BF16, (SMALL || 4 * 2 > 4) ? 1 : 2>(p, jb, gtile, sh); break;
+        case 2 * 8 + 4: if constexpr (!SMALL) wgrad_macro_tile<2, 4, BF16, (SMALL || 2 * 4 > 4) ? 1 : 2>(p, jb, gtile, sh); break;
+        case 4 * 8 + 1: wgrad_macro_tile<4, 1, BF16, (SMALL || 4 * 1 > 4) ? 1 : 2>(p, jb, gtile, sh); break;
+        case 1 * 8 + 4: wgrad_macro_tile<1, 4, BF16, (SMALL || 1 * 4 > 4) ? 1 : 2>(p, jb, gtile, sh); break;
+        case 2 * 8 + 2: wgrad_macro_tile<2, 2, BF16, (SMALL || 2 * 2 > 4) ? 1 : 2>(p, jb, gtile, sh); break;
+        case 2 * 8 + 1: wgrad_macro_tile<2, 1, BF16, (SMALL || 2 * 1 > 4) ? 1 : 2>(p, jb, gtile, sh); break;
+        case 1 * 8 + 2: wgrad_macro_tile<1, 2, BF16, (SMALL || 1 * 2 > 4) ? 1 : 2>(p, jb, gtile, sh); break;
+        default: wgrad_macro_tile<1, 1, BF16, (SMALL || 1 * 1 > 4) ? 1 : 2>(p, jb, gtile, sh); break;
     }
 }
 
