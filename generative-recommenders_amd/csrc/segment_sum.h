@@ -56,7 +56,7 @@ struct WeightedRows {
     // The coefficient rides through the sort next to the source row number, so the run loop reads it from the
     // sorted stream instead of chasing a random 4-byte load per entry.
     using Val = uint2;                  // (source row i, coefficient bits)
-    static constexpr int kPiece = 128;
+    static constexpr int kPiece = 256;  // (128: twice the pieces to join; 512: too few blocks to balance the groups)
     static constexpr bool kBalanced = true;    // runs here are hundreds of entries long: one group per block of kPiece
     const float* rows;      // (n_src, d)
     const float* coef;      // (n_src, coef_stride)
