@@ -1516,6 +1516,10 @@ static int linear_launch(LinearParams& p, int n_z, hipStream_t stream) {
     const int copies = g_linear_split ? 2 : 1;
     int n_chunk = std::min<int>(256, (60 * 1024 / (kp * 2 * copies)) / 32 * 32);
     n_chunk = std::min<int>(n_chunk, (int)((N + 31) / 32 * 32));
+    // A product over few tokens (the per-sequence projections of the fusion tail: B rows) is all weight staging: a
+    // handful of workgroups would each convert the whole panel.  32 output columns per workgroup spread that work
+    // (the tokens are re-read per panel, which costs nothing at this size).
+    if (hmx_ceil_div(hmx_ceil_div(T, 32), 4) < 64) n_chunk = 32;
     p.n_chunk = n_chunk;
     const size_t lds = (size_t)n_chunk * kp * 2 * copies;
     // Every workgroup first stages its weight panel in LDS.  For K > 64 that panel is large enough that spreading the
