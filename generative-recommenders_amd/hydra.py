@@ -185,6 +185,35 @@ class HydraBlock(_HydraBlockBase):
     first = False
 
 
+class _ScaleWindows(torch.autograd.Function):
+    """(sequence[:, -sw:], sequence[:, -mw:], sequence) for the three encoders of hydra3.py:528-530.  Through plain
+    slicing the backward pass builds two zero-filled (B, L, d) tensors, copies a window into each and adds all three;
+    here the two window gradients are added onto the tails of the long encoder's input gradient (which this node
+    owns: it is the fresh output of that encoder's backward kernel)."""
+
+    @staticmethod
+    def forward(ctx, sequence, sw, mw):
+        ctx.windows = (sw, mw)
+        return sequence[:, -sw:].contiguous(), sequence[:, -mw:].contiguous(), sequence.view_as(sequence)
+
+    @staticmethod
+    def backward(ctx, d_short, d_mid, d_long):
+        sw, mw = ctx.windows
+        some = d_long if d_long is not None else (d_mid if d_mid is not None else d_short)
+        if some is None:
+            return None, None, None
+        if d_long is None:
+            B, d = some.shape[0], some.shape[2]
+            d_long = some.new_zeros(B, max(sw, mw), d)          # only reached when the long encoder is cut off
+        elif not d_long.is_contiguous():
+            d_long = d_long.contiguous()
+        if d_short is not None:
+            d_long[:, -sw:] += d_short
+        if d_mid is not None:
+            d_long[:, -mw:] += d_mid
+        return d_long, None, None
+
+
 class MultiScaleUserEncoder(nn.Module):
     """hydra3.py:460-548.  The three HydraBlocks, the attention's projections, the one-query attention, the gate's
     Linear, the gated mix, the RMSNorm and the output projection run on the HIP kernels; the final broadcast add
@@ -207,9 +236,13 @@ class MultiScaleUserEncoder(nn.Module):
         sw, mw = min(10, L), min(25, L)
         sm = padding_mask[:, -sw:].contiguous() if padding_mask is not None else None
         mm = padding_mask[:, -mw:].contiguous() if padding_mask is not None else None
-        short = self.short_term_encoder(sequence[:, -sw:].contiguous(), sm)
-        mid = self.mid_term_encoder(sequence[:, -mw:].contiguous(), mm)
-        long_ = self.long_term_encoder(sequence, padding_mask)
+        if sequence.requires_grad:
+            short_in, mid_in, long_in = _ScaleWindows.apply(sequence, sw, mw)
+        else:
+            short_in, mid_in, long_in = sequence[:, -sw:].contiguous(), sequence[:, -mw:].contiguous(), sequence
+        short = self.short_term_encoder(short_in, sm)
+        mid = self.mid_term_encoder(mid_in, mm)
+        long_ = self.long_term_encoder(long_in, padding_mask)
         lay = self.long_term_encoder.fused_layout(sequence.device)
         if lay is not None and lay.widened and long_.shape[-1] == lay.dp:     # widened input: the tail runs at d
             short, mid = (lay.narrow(t[:, -1]).unsqueeze(1) for t in (short, mid))
