@@ -1896,13 +1896,193 @@ __global__ __launch_bounds__(64) void attn1q_bwd_kernel(const float* __restrict_
     }
 }
 
+// Row-parallel form of the two kernels above: one workgroup per sequence, every k / v row read (and every dk / dv row
+// written) 16 bytes per lane by next_pow2(d / 4) neighbouring lanes, four rows in flight per lane; the per-head dot
+// products are finished with shuffles inside the head's lanes, the weighted sums over positions by row groups whose
+// partial sums are added in group order.  Needs head widths whose quarter is a power of two (hd = 32, 64, ...) and
+// H * L <= kAttnRowsMaxHL; other shapes use the kernels above.  (One wave per (sequence, head) with a lane per
+// position read its rows four bytes at a time: 39 + 61 us per step at B = 1024, L = 100, d = 64.)
+constexpr int kAttnRowsMaxHL = 8192;
+
+__device__ __forceinline__ float head_lanes_sum(float v, int lanes) {      // lanes: power of two <= 64, aligned groups
+    for (int off = lanes >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// scores s_sh[h * L + l] = scale_or_1 * <vec_h, row_l[col0 + h * hd ...]> for all l, h (vec: q or dout; rows: k or v)
+__device__ __forceinline__ void attn_rows_dots(const float4* __restrict__ rows4, int row_f4, int col0_f4, const float4 vq,
+                                               int L, int cpr, int lpr, int hl, float mul, float* __restrict__ s_sh) {
+    const int c = threadIdx.x % lpr, g = threadIdx.x / lpr, rp = 256 / lpr;
+    const bool c_ok = c < cpr;
+    const int h = c / hl;
+    for (int l0 = 0; l0 < L; l0 += 4 * rp) {
+        float4 kr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = l0 + u * rp + g;
+            kr[u] = (c_ok && l < L) ? rows4[(int64_t)l * row_f4 + col0_f4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = l0 + u * rp + g;
+            float part = kr[u].x * vq.x + kr[u].y * vq.y + kr[u].z * vq.z + kr[u].w * vq.w;
+            part = head_lanes_sum(part, hl);
+            if (c_ok && l < L && (c % hl) == 0) s_sh[h * L + l] = part * mul;
+        }
+    }
+}
+
+// acc4 = sum_l w_sh[h * L + l] * rows_l[col0 + 4 c ...] for this lane's column chunk, rows dealt to the row groups and the
+// groups' partial sums added in group order; valid in the threads of group 0
+__device__ __forceinline__ float4 attn_rows_weighted_sum(const float4* __restrict__ rows4, int row_f4, int col0_f4, int L,
+                                                         int cpr, int lpr, int hl, const float* __restrict__ w_sh,
+                                                         float4* __restrict__ red /* [256] */) {
+    const int c = threadIdx.x % lpr, g = threadIdx.x / lpr, rp = 256 / lpr;
+    const bool c_ok = c < cpr;
+    const int h = c_ok ? c / hl : 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l0 = g; l0 < L; l0 += 4 * rp) {
+        float4 vr[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = l0 + u * rp;
+            const bool ok = c_ok && l < L;
+            vr[u] = ok ? rows4[(int64_t)l * row_f4 + col0_f4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            w[u] = ok ? w_sh[h * L + l] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc.x = __builtin_fmaf(w[u], vr[u].x, acc.x);
+            acc.y = __builtin_fmaf(w[u], vr[u].y, acc.y);
+            acc.z = __builtin_fmaf(w[u], vr[u].z, acc.z);
+            acc.w = __builtin_fmaf(w[u], vr[u].w, acc.w);
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g == 0) {
+        for (int gg = 0; gg < rp; ++gg) {
+            const float4 o = red[gg * lpr + c];
+            tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w;
+        }
+    }
+    __syncthreads();
+    return tot;
+}
+
+__global__ __launch_bounds__(256) void attn1q_rows_fwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                              const float* __restrict__ drop, int L, int d, int H,
+                                                              int lpr, float* __restrict__ p_out, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char attn_smem[];
+    float* s_sh = reinterpret_cast<float*>(attn_smem);                       // [H][L]
+    float4* red = reinterpret_cast<float4*>(attn_smem + (size_t)((H * L + 3) / 4 * 4) * sizeof(float));   // [256]
+    const int b = blockIdx.x, cpr = d / 4, hd = d / H, hl = hd / 4;
+    const int c = threadIdx.x % lpr, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float4* kv4 = reinterpret_cast<const float4*>(kv) + (int64_t)b * L * 2 * cpr;
+    const float4 q4 = c < cpr ? reinterpret_cast<const float4*>(q)[(int64_t)b * cpr + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    attn_rows_dots(kv4, 2 * cpr, 0, q4, L, cpr, lpr, hl, scale, s_sh);
+    __syncthreads();
+    for (int h = wave; h < H; h += 4) {                                      // softmax of a head: one wave
+        float* sh = s_sh + h * L;
+        float mx = -INFINITY;
+        for (int l = lane; l < L; l += 64) mx = fmaxf(mx, sh[l]);
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float sum = 0.f;
+        for (int l = lane; l < L; l += 64) {
+            const float e = expf(sh[l] - mx);
+            sh[l] = e;
+            sum += e;
+        }
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        const float inv = 1.0f / sum;
+        for (int l = lane; l < L; l += 64) {
+            const float pr = sh[l] * inv;
+            p_out[((int64_t)b * H + h) * L + l] = pr;
+            sh[l] = drop ? pr * drop[((int64_t)b * H + h) * L + l] : pr;
+        }
+    }
+    __syncthreads();
+    const float4 o4 = attn_rows_weighted_sum(kv4, 2 * cpr, cpr, L, cpr, lpr, hl, s_sh, red);
+    if (threadIdx.x < lpr && c < cpr) reinterpret_cast<float4*>(out)[(int64_t)b * cpr + c] = o4;
+}
+
+__global__ __launch_bounds__(256) void attn1q_rows_bwd_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                              const float* __restrict__ drop, const float* __restrict__ p_in,
+                                                              const float* __restrict__ dout, int L, int d, int H, int lpr,
+                                                              float* __restrict__ dq, float* __restrict__ dkv) {
+    extern __shared__ __attribute__((aligned(16))) char attn_smem[];
+    const int hl_pad = (H * L + 3) / 4 * 4;
+    float* ds_sh = reinterpret_cast<float*>(attn_smem);                      // [H][L] d score
+    float* wv_sh = ds_sh + hl_pad;                                           // [H][L] weight that multiplied v (p * drop)
+    float4* red = reinterpret_cast<float4*>(wv_sh + hl_pad);                 // [256]
+    const int b = blockIdx.x, cpr = d / 4, hd = d / H, hl = hd / 4;
+    const int c = threadIdx.x % lpr, g = threadIdx.x / lpr, rp = 256 / lpr, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const float4* kv4 = reinterpret_cast<const float4*>(kv) + (int64_t)b * L * 2 * cpr;
+    float4* dkv4 = reinterpret_cast<float4*>(dkv) + (int64_t)b * L * 2 * cpr;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 q4 = c < cpr ? reinterpret_cast<const float4*>(q)[(int64_t)b * cpr + c] : zero4;
+    const float4 do4 = c < cpr ? reinterpret_cast<const float4*>(dout)[(int64_t)b * cpr + c] : zero4;
+    // dw[l] = drop[l] * <dout, v_l>;  dot = sum_l p[l] dw[l];  ds[l] = p[l] (dw[l] - dot) / sqrt(hd)
+    attn_rows_dots(kv4, 2 * cpr, cpr, do4, L, cpr, lpr, hl, 1.0f, ds_sh);
+    __syncthreads();
+    for (int h = wave; h < H; h += 4) {
+        const float* pb = p_in + ((int64_t)b * H + h) * L;
+        const float* db = drop ? drop + ((int64_t)b * H + h) * L : nullptr;
+        float dot = 0.f;
+        for (int l = lane; l < L; l += 64) {
+            const float m = db ? db[l] : 1.0f;
+            const float dw = ds_sh[h * L + l] * m;
+            ds_sh[h * L + l] = dw;
+            wv_sh[h * L + l] = pb[l] * m;
+            dot += pb[l] * dw;
+        }
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        for (int l = lane; l < L; l += 64) ds_sh[h * L + l] = pb[l] * (ds_sh[h * L + l] - dot) * scale;
+    }
+    __syncthreads();
+    const float4 dq4 = attn_rows_weighted_sum(kv4, 2 * cpr, 0, L, cpr, lpr, hl, ds_sh, red);
+    if (threadIdx.x < lpr && c < cpr) reinterpret_cast<float4*>(dq)[(int64_t)b * cpr + c] = dq4;
+    if (c < cpr) {
+        const int h = c / hl;
+        for (int l = g; l < L; l += rp) {
+            const float a = ds_sh[h * L + l], w = wv_sh[h * L + l];
+            dkv4[(int64_t)l * 2 * cpr + c] = make_float4(a * q4.x, a * q4.y, a * q4.z, a * q4.w);              // d k
+            dkv4[(int64_t)l * 2 * cpr + cpr + c] = make_float4(w * do4.x, w * do4.y, w * do4.z, w * do4.w);    // d v
+        }
+    }
+}
+
+// lanes per row of the row-parallel form, or 0 when the shape takes the wave-per-head kernels
+static int attn_rows_lpr(int64_t L, int64_t d, int64_t H, const void* a, const void* b, const void* c2, const void* e) {
+    if (d % 4 || d % H || d > 256 || H * L > kAttnRowsMaxHL) return 0;
+    const int64_t hd = d / H;
+    if (hd % 4) return 0;
+    const int64_t hl = hd / 4;
+    if (hl & (hl - 1)) return 0;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c2) |
+         reinterpret_cast<uintptr_t>(e)) & 15) return 0;
+    int lpr = 1;
+    while (lpr < d / 4) lpr *= 2;
+    return lpr;
+}
+
 extern "C" int hmx_attn1q_fwd(const float* q, const float* kv, const float* drop, int64_t B, int64_t L, int64_t d,
                               int64_t H, float* p_out, float* out, void* stream) {
     HMX_ENTER();
     if (B == 0) return HMX_OK;
     if (!q || !kv || !p_out || !out || L <= 0 || L > kAttnMaxL || d <= 0 || H <= 0 || d % H) return HMX_EINVAL;
-    hipLaunchKernelGGL(attn1q_fwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, q, kv, drop, (int)L,
-                       (int)d, (int)H, p_out, out);
+    if (const int lpr = attn_rows_lpr(L, d, H, q, kv, out, nullptr)) {
+        const size_t lds = (size_t)((H * L + 3) / 4 * 4) * sizeof(float) + 256 * sizeof(float4);
+        hipLaunchKernelGGL(attn1q_rows_fwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, q, kv, drop, (int)L,
+                           (int)d, (int)H, lpr, p_out, out);
+    } else {
+        hipLaunchKernelGGL(attn1q_fwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, q, kv, drop, (int)L,
+                           (int)d, (int)H, p_out, out);
+    }
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }
@@ -1913,8 +2093,15 @@ extern "C" int hmx_attn1q_bwd(const float* q, const float* kv, const float* drop
     if (B == 0) return HMX_OK;
     if (!q || !kv || !p || !dout || !dq || !dkv || L <= 0 || L > kAttnMaxL || d <= 0 || H <= 0 || d % H)
         return HMX_EINVAL;
-    hipLaunchKernelGGL(attn1q_bwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, q, kv, drop, p, dout,
-                       (int)L, (int)d, (int)H, dq, dkv);
+    if (const int lpr = attn_rows_lpr(L, d, H, q, kv, dout, dkv); lpr != 0 && (reinterpret_cast<uintptr_t>(dq) & 15) == 0) {
+        const size_t lds = 2 * (size_t)((H * L + 3) / 4 * 4) * sizeof(float) + 256 * sizeof(float4);
+        hmx_allow_dynamic_lds(reinterpret_cast<const void*>(&attn1q_rows_bwd_kernel), 2 * kAttnRowsMaxHL * 4 + 4096 + 64);
+        hipLaunchKernelGGL(attn1q_rows_bwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, q, kv, drop, p, dout,
+                           (int)L, (int)d, (int)H, lpr, dq, dkv);
+    } else {
+        hipLaunchKernelGGL(attn1q_bwd_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, q, kv, drop, p, dout,
+                           (int)L, (int)d, (int)H, dq, dkv);
+    }
     HMX_CHECK_LAUNCH();
     return HMX_OK;
 }

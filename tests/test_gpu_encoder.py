@@ -825,7 +825,9 @@ def test_pscan_rejects_cpu_tensors():
 
 # ---- one-query attention of the fusion tail (hydra3.py:528-533) alone, fp32-tight against torch's own module
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,L,d,Hh", [(5, 100, 64, 2), (3, 7, 16, 2), (2, 512, 128, 4), (4, 1, 32, 2)])
+# (the last two shapes -- head widths 30 and 48 -- take the wave-per-head kernels, the others the row-parallel ones)
+@pytest.mark.parametrize("B,L,d,Hh", [(5, 100, 64, 2), (3, 7, 16, 2), (2, 512, 128, 4), (4, 1, 32, 2), (3, 50, 60, 2),
+                                      (2, 40, 96, 2)])
 def test_attn1q_matches_multihead_attention(B, L, d, Hh):
     torch.manual_seed(B * 1000 + L)
     mha = torch.nn.MultiheadAttention(d, Hh, dropout=0.0, batch_first=True).eval()
