@@ -119,21 +119,32 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 }
 
 // one workgroup per digit: its row of tile counts becomes the row of exclusive prefixes; totals[digit] = the sum.
-// The row is walked 256 counts at a time (neighbouring threads read neighbouring counts) with a running base.
+// The row is walked 1024 counts at a time (a thread owns four consecutive ones) with a running base; the next
+// chunk's counts are on their way during the scan of this one.
 __global__ __launch_bounds__(kThreads) void radix_scan_kernel(uint32_t* __restrict__ hist, int n_tiles,
                                                               uint32_t* __restrict__ totals) {
     __shared__ uint32_t wave_sums[kWaves];
     uint32_t* row = hist + (int64_t)blockIdx.x * n_tiles;
     const int tid = threadIdx.x;
     uint32_t base = 0;
-    uint32_t next = tid < n_tiles ? row[tid] : 0;
-    for (int c0 = 0; c0 < n_tiles; c0 += kThreads) {
-        const uint32_t v = next;
-        const int i = c0 + tid;
-        next = i + kThreads < n_tiles ? row[i + kThreads] : 0;      // the next chunk is on its way during this scan
+    uint32_t next[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) next[e] = 4 * tid + e < n_tiles ? row[4 * tid + e] : 0;
+    for (int c0 = 0; c0 < n_tiles; c0 += 4 * kThreads) {
+        uint32_t v[4];
+        const int i = c0 + 4 * tid;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = next[e];
+            next[e] = i + 4 * kThreads + e < n_tiles ? row[i + 4 * kThreads + e] : 0;
+        }
         uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, wave_sums, &total);
-        if (i < n_tiles) row[i] = base + ex;
+        uint32_t ex = base + block_exclusive_scan(v[0] + v[1] + v[2] + v[3], wave_sums, &total);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i + e < n_tiles) row[i + e] = ex;
+            ex += v[e];
+        }
         base += total;
     }
     if (tid == 0) totals[blockIdx.x] = base;
