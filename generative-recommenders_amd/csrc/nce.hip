@@ -304,13 +304,28 @@ __global__ __launch_bounds__(256) void nce_bwd_light_kernel(NceParams p) {
     const float gr = p.grad_row_loss[i], lse = p.lse[i];
     const float g = gr * p.inv_temp * p.q_inv[i];
     float* row = p.logits + i * C;
-    for (int vs = lane; vs < walk.n_walk; vs += 64) {
-        const int slot = walk.real(vs);
-        row[slot] = (__expf(row[slot] - lse) - (slot == 0 ? 1.f : 0.f)) * g * walk.copies(vs);
+    // the row's logits are requested eight chunks (512 slots) at a time before the first is used: a wave lives for
+    // one round trip of its row instead of one per chunk
+    const float4 u = lane < p.cpr ? reinterpret_cast<const float4*>(p.dq_unit)[i * p.cpr + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v0 = 0; v0 < walk.n_walk; v0 += 8 * 64) {
+        float lg[8];
+        int slot[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int vs = v0 + 64 * k + lane;
+            slot[k] = vs < walk.n_walk ? walk.real(vs) : -1;
+            lg[k] = slot[k] >= 0 ? row[slot[k]] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int vs = v0 + 64 * k + lane;
+            if (slot[k] >= 0) row[slot[k]] = (__expf(lg[k] - lse) - (slot[k] == 0 ? 1.f : 0.f)) * g * walk.copies(vs);
+        }
     }
-    for (int c = lane; c < p.cpr; c += 64) {
-        const float4 u = reinterpret_cast<const float4*>(p.dq_unit)[i * p.cpr + c];
-        reinterpret_cast<float4*>(p.dq)[i * p.cpr + c] = vscale(gr, u);
+    if (lane < p.cpr) reinterpret_cast<float4*>(p.dq)[i * p.cpr + lane] = vscale(gr, u);
+    for (int c = lane + 64; c < p.cpr; c += 64) {
+        const float4 w = reinterpret_cast<const float4*>(p.dq_unit)[i * p.cpr + c];
+        reinterpret_cast<float4*>(p.dq)[i * p.cpr + c] = vscale(gr, w);
     }
 }
 
