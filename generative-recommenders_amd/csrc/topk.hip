@@ -754,7 +754,32 @@ __global__ __launch_bounds__(64) void group_threshold_kernel(const float* __rest
         if (row >= 0 && row < n_rows) {
             const float* tv = t_f32 + row * d;
             sc = 0.f;
-            for (int c = 0; c < d; ++c) sc = __builtin_fmaf(qv[c], tv[c], sc);
+            if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(tv) | reinterpret_cast<uintptr_t>(qv)) & 15) == 0) {
+                // the same k-ordered chain, its operands read 16 bytes at a time and eight reads ahead (a lane walks a
+                // random row alone: four bytes per dependent step made this kernel 0.29 ms at 512 exclusions x d 128)
+                const float4* t4 = reinterpret_cast<const float4*>(tv);
+                const float4* q4 = reinterpret_cast<const float4*>(qv);
+                for (int c0 = 0; c0 < d / 4; c0 += 8) {
+                    float4 a[8], b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + u < d / 4 ? c0 + u : d / 4 - 1;
+                        a[u] = q4[c];
+                        b[u] = t4[c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (c0 + u < d / 4) {
+                            sc = __builtin_fmaf(a[u].x, b[u].x, sc);
+                            sc = __builtin_fmaf(a[u].y, b[u].y, sc);
+                            sc = __builtin_fmaf(a[u].z, b[u].z, sc);
+                            sc = __builtin_fmaf(a[u].w, b[u].w, sc);
+                        }
+                    }
+                }
+            } else {
+                for (int c = 0; c < d; ++c) sc = __builtin_fmaf(qv[c], tv[c], sc);
+            }
         }
         sh_e[e] = sc;
     }
