@@ -35,6 +35,24 @@ __device__ __forceinline__ void vadd(float4& a, const float4& b) { a.x += b.x; a
 __device__ __forceinline__ void vadd(float& a, const float& b) { a += b; }
 
 
+// n / d for 32-bit n and a divisor fixed per launch, as a multiply-high and two shifts (Granlund-Montgomery round-up
+// form: exact for every 32-bit n); the hardware has no integer divide, and the sort's first pass divides per entry.
+struct FastDiv {
+    uint32_t m, s1, s2, d;
+    FastDiv() : m(0), s1(0), s2(0), d(1) {}
+    explicit FastDiv(uint32_t div) : d(div ? div : 1) {
+        int l = 0;
+        while (((uint64_t)1 << l) < d) ++l;
+        m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+        s1 = l > 0 ? 1 : 0;
+        s2 = l > 0 ? l - 1 : 0;
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const {
+        const uint32_t t = __umulhi(m, n);
+        return (t + ((n - t) >> s1)) >> s2;
+    }
+};
+
 // value(entry) = rows[entry]: the plain scatter-add of materialised gradient rows
 struct PlainRows {
     using Val = uint32_t;               // what travels with the key through the sort: the entry number
@@ -61,8 +79,11 @@ struct WeightedRows {
     const float* rows;      // (n_src, d)
     const float* coef;      // (n_src, coef_stride)
     int per_row, coef_stride, col0;
+    FastDiv by_per_row;
+    WeightedRows(const float* rows_, const float* coef_, int per_row_, int coef_stride_, int col0_)
+        : rows(rows_), coef(coef_), per_row(per_row_), coef_stride(coef_stride_), col0(col0_), by_per_row((uint32_t)per_row_) {}
     __device__ __forceinline__ Val make_val(int64_t e) const {
-        const uint32_t i = (uint32_t)e / (uint32_t)per_row, sidx = (uint32_t)e - i * (uint32_t)per_row;   // e < 2^32 (checked by the sort): no 64-bit division
+        const uint32_t i = by_per_row.div((uint32_t)e), sidx = (uint32_t)e - i * (uint32_t)per_row;   // e < 2^32 (checked by the sort)
         return make_uint2(i, __float_as_uint(coef[(int64_t)i * coef_stride + col0 + sidx]));
     }
     __device__ __forceinline__ int64_t row_index(Val v) const { return (int64_t)v.x; }
@@ -84,12 +105,14 @@ struct IdSource {
     const int32_t* i32;
     uint32_t per_row;
     int skip_self;
+    FastDiv by_per_row;
     IdSource(const int64_t* ids) : i64(ids), i32(nullptr), per_row(1), skip_self(0) {}
-    IdSource(const int32_t* ids, int64_t per_row_, int skip) : i64(nullptr), i32(ids), per_row((uint32_t)per_row_), skip_self(skip) {}
+    IdSource(const int32_t* ids, int64_t per_row_, int skip)
+        : i64(nullptr), i32(ids), per_row((uint32_t)per_row_), skip_self(skip), by_per_row((uint32_t)per_row_) {}
     __device__ __forceinline__ int64_t at(int64_t e) const {
         if (i64 != nullptr) return i64[e];
         int64_t r = i32[e];
-        if (skip_self) r += (r >= (int64_t)((uint32_t)e / per_row)) ? 1 : 0;     // e < 2^32 (checked by the sort)
+        if (skip_self) r += (r >= (int64_t)by_per_row.div((uint32_t)e)) ? 1 : 0;     // e < 2^32 (checked by the sort)
         return r;
     }
 };
