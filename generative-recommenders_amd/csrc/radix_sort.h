@@ -75,11 +75,18 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(In in, int64_t n, 
     __syncthreads();
     constexpr int kTile = kThreads * IPT;
     const int64_t base = (int64_t)blockIdx.x * kTile;
-#pragma unroll 4
+    // all of a thread's keys are requested before the first is counted
+    uint32_t dg[IPT];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+        const int64_t i = base + r * kThreads + tid;
+        dg[r] = i < n ? ((in.key(i) >> shift) & mask) : 0;
+    }
+#pragma unroll
     for (int r = 0; r < IPT; ++r) {
         const int64_t i = base + r * kThreads + tid;
         const bool valid = i < n;
-        const uint32_t d = valid ? ((in.key(i) >> shift) & mask) : 0;
+        const uint32_t d = dg[r];
         // LDS atomics (integer: the counts do not depend on their order).  A wave whose lanes all hold the same digit
         // -- runs of equal ids, sentinels -- would serialise 64 ways on one counter, so that case adds once.
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
