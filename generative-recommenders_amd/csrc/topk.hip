@@ -693,7 +693,6 @@ __global__ __launch_bounds__(64, 2) void group_max_kernel(CoarseParams p, int ti
     const uint16_t* ap = p.t_bf16 + ((int64_t)split * tile_step * 32 + j) * p.dpad + 8 * h;
     const int64_t stride = 32 * (int64_t)p.dpad * tile_step * p.n_splits;
     float best[2] = {kNegInf, kNegInf};
-    short8 a0[KS], a1[KS];
     auto load_tile = [&](short8(&dst)[KS], int t) {
         const uint16_t* src = ap + (int64_t)t * stride;
 #pragma unroll
@@ -710,18 +709,20 @@ __global__ __launch_bounds__(64, 2) void group_max_kernel(CoarseParams p, int ti
         for (int r = 3; r < 15; r += 3) m = fmaxf(m, fmaxf(fmaxf(acc[r], acc[r + 1]), acc[r + 2]));
         into = fmaxf(into, fmaxf(m, acc[15]));
     };
-    int t = 0;
-    if (tiles_per_split > 0) load_tile(a0, 0);
-    for (; t + 2 < tiles_per_split; t += 2) {       // even tiles feed best[0], odd ones best[1]
-        load_tile(a1, t + 1);
-        score_tile(a0, best[0]);
-        load_tile(a0, t + 2);
-        score_tile(a1, best[1]);
-    }
-    if (t < tiles_per_split) score_tile(a0, best[0]);
-    if (t + 1 < tiles_per_split) {
-        load_tile(a1, t + 1);
-        score_tile(a1, best[1]);
+    // A ring of kDepth sampled tiles in flight (a wave is alone with its loads: with two, a tile's MFMAs -- a hundred
+    // cycles -- waited a whole memory round trip for the next tile).  Even tiles feed best[0], odd ones best[1].
+    constexpr int kDepth = KS <= 4 ? 6 : 4;            // an even number
+    short8 ring[kDepth][KS];
+#pragma unroll
+    for (int s = 0; s < kDepth - 1; ++s)
+        if (s < tiles_per_split) load_tile(ring[s], s);
+    for (int t0 = 0; t0 < tiles_per_split; t0 += kDepth) {
+#pragma unroll
+        for (int s = 0; s < kDepth; ++s) {
+            const int t = t0 + s;
+            if (t + kDepth - 1 < tiles_per_split) load_tile(ring[(s + kDepth - 1) % kDepth], t + kDepth - 1);
+            if (t < tiles_per_split) score_tile(ring[s], best[s & 1]);
+        }
     }
     float* o = gmax + ((int64_t)qtile * 32 + j) * (4 * p.n_splits) + 4 * split + 2 * h;
     o[0] = best[0];
