@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies the newest outputs of scripts/gpu_profile_round.sh a|b (gpurun_out/r3) into profiles/ under their round-3 names.
+# Copies the newest outputs of scripts/gpu_profile_round.sh a|b (gpurun_out/r3) into profiles/ under the r03_ names.
 set -e
 R=gpurun_out/r3
 newest() { find "$1" -name "$2" -printf "%T@ %p\n" | sort -n | tail -1 | cut -d' ' -f2; }
