@@ -17,7 +17,7 @@ if [ "$1" = "a" ]; then
 else
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train -- python3 bench.py --workload train --steps 4 --warmup 2 --no-cpu-baseline > $OUT/prof_train.log 2>&1
   python3 scripts/kernel_groups.py $OUT/prof_train 6 12
-  timeout -k 10 500 python3 -u bench.py --workload train --batch 512 --seq-len 512 --dim 128 --steps 5 --warmup 2 > $OUT/train_config4.json 2> $OUT/train_config4.err
+  timeout -k 10 500 python3 -u bench.py --workload train --batch 512 --seq-len 512 --dim 128 --steps 20 --warmup 5 > $OUT/train_config4.json 2> $OUT/train_config4.err
   tail -n 1 $OUT/train_config4.json | cut -c1-300
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_c4 -- python3 bench.py --workload train --batch 512 --seq-len 512 --dim 128 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_train_c4.log 2>&1
   python3 scripts/kernel_groups.py $OUT/prof_train_c4 6 12
