@@ -54,6 +54,7 @@ class _InputAssembly(torch.autograd.Function):
         ctx.params = (item_w, user_w, pos_w, W, b, time_rows, action_rows, dwell_rows)
         ctx.cfg = (L, time_span, scale, small_padding_idx, pre is not None)
         ctx.mark_non_differentiable(pm, pos, tb)
+        ctx.set_materialize_grads(False)      # no zero tensors built for the three index outputs in every backward pass
         return out, pm, pos, tb
 
     @staticmethod
@@ -62,6 +63,8 @@ class _InputAssembly(torch.autograd.Function):
         item_w, user_w, pos_w, W, b, time_rows, action_rows, dwell_rows = ctx.params
         L, time_span, scale, small_pad, has_pre = ctx.cfg
         T, d, ds = idc.numel(), Wc.shape[0], item_w.shape[1]
+        if dout is None:
+            return (None,) * 18
         dev = dout.device
         dout = _f32c(dout).reshape(T, d)
         g, gs = torch.empty_like(dout), torch.empty_like(dout)

@@ -182,6 +182,7 @@ class _BlockPre(torch.autograd.Function):
         ctx.cfg = (L, lay, first, eps, packed, link)
         ctx.params = (scale1, W1, b1) + tuple(Win)
         ctx.mark_non_differentiable(rstd1)
+        ctx.set_materialize_grads(False)      # backward takes None for absent gradients: no (T) zeros built for rstd1
         return x_in, z, y2, rstd1
 
     @staticmethod

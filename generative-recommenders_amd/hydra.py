@@ -431,7 +431,12 @@ def compute_mixed_contrastive_loss(log_feats, pos_embs, loss_mask, item_table=No
     d = log_feats.shape[-1]
     if M == 0:
         return torch.tensor(0.0, device=device, requires_grad=True)
-    q, k = _TakeRows.apply(log_feats.reshape(-1, d), rows), _TakeRows.apply(pos_embs.reshape(-1, d), rows)
+    if M == log_feats.numel() // d:
+        # every position carries a loss row (distinct, ascending row numbers: rows == arange): the selection of
+        # hydra3.py:866-868 is the identity, so no copy forward and no zero-filled scatter backward
+        q, k = log_feats.reshape(-1, d), pos_embs.reshape(-1, d)
+    else:
+        q, k = _TakeRows.apply(log_feats.reshape(-1, d), rows), _TakeRows.apply(pos_embs.reshape(-1, d), rows)
     if predrawn is not None:
         hard_ids, inb = predrawn
         return ops.fused_nce_rows(q, k, item_table, hard_ids, inb, temperature, normalize).mean()
