@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from generative_recommenders_amd import enc_ops, hydra as H, ops, synth  # noqa: E402
 from generative_recommenders_amd.optim import HmxAdamW  # noqa: E402
 
-B, L, d = 1024, 100, 64
+B, L, d = 1024, 100, int(os.environ.get("PROBE_DIM", "64"))
 dev = torch.device("cuda", 0)
 model = H.build_model(1_000_000, 4_000_000, d=d, L=L, dropout=0.2, device=dev, seed=1234).train()
 ops.set_fused_table_grad(True)
