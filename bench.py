@@ -258,8 +258,13 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             from bench_train import run_train
-            t = run_train(args, world, rank)
-            out["train_step"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "fwd_bwd_ms", "config",
+            import copy
+            targs = copy.copy(args)
+            # a search step is 0.4 s and a train step 16 ms: the train half takes its own counts (with the search's
+            # 3 + 1 the first timed steps still carry the allocator's warm-up), stated in the sub-line
+            targs.steps, targs.warmup = max(args.steps, 20), max(args.warmup, 5)
+            t = run_train(targs, world, rank)
+            out["train_step"] = {k: t[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "fwd_bwd_ms", "config",
                                                    "roofline", "encoder", "other_kernels", "cpu_baseline", "loss") if k in t}
     if rank == 0:
         print(json.dumps(out), flush=True)
