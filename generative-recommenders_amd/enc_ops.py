@@ -284,21 +284,25 @@ class _Linear(torch.autograd.Function):
     """y = ((x * in_mask) W[:, col_off:col_off + K]^T + b + c1 r1 + c2 r2) * out_mask   (at most one of the masks)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, in_mask, out_mask, r1, c1, r2, c2, col_off=0):
+    def forward(ctx, x, weight, bias, in_mask, out_mask, r1, c1, r2, c2, col_off=0, rows=None):
         _need_cuda(x, weight)
         assert in_mask is None or out_mask is None
-        x, w = _f32c(x), _f32c(weight)
+        x, w_full = _f32c(x), _f32c(weight)
+        row0, row1 = rows if rows is not None else (0, w_full.shape[0])
+        w = w_full[row0:row1]                       # the output rows used (a view: rows of a row-major matrix)
+        b_used = bias[row0:row1] if (bias is not None and rows is not None) else bias
         T, K = x.shape
         N, ldw = w.shape
         assert ldw >= col_off + K
         r1 = _f32c(r1) if r1 is not None else None
         r2 = _f32c(r2) if r2 is not None else None
         y = _empty(T, N, like=x)
-        _linear_raw(hmx.ptr(x), K, hmx.ptr(w) + 4 * col_off, ldw, 1, bias, T, N, K, hmx.ptr(y), N, r1, c1, r2, c2,
+        _linear_raw(hmx.ptr(x), K, hmx.ptr(w) + 4 * col_off, ldw, 1, b_used, T, N, K, hmx.ptr(y), N, r1, c1, r2, c2,
                     in_mask, out_mask)
         ctx.save_for_backward(x, w, in_mask, out_mask)
         ctx.c = (c1, c2)
         ctx.col_off = col_off
+        ctx.rows = (row0, row1, w_full.shape[0])
         ctx.has_bias = bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         return y
@@ -308,6 +312,7 @@ class _Linear(torch.autograd.Function):
         x, w, in_mask, out_mask = ctx.saved_tensors
         T, K = x.shape
         N, ldw = w.shape
+        row0, row1, n_all = ctx.rows
         g = _f32c(dy)
         if out_mask is not None:
             g = combine([g], [1.0], out_mask)
@@ -322,26 +327,36 @@ class _Linear(torch.autograd.Function):
         tb = _param_grad_target(ctx.bparam) if want_db else None
         if tw is not None and (tb is not None or not want_db):
             # direct mode: queued, added into .grad by a batched launch; nothing is returned to autograd
-            _wgrad_queue.add(g, 0, N, x, 0, K, in_mask, T, N, K, tw, ctx.col_off, ldw, tb, 0)
+            _wgrad_queue.add(g, 0, N, x, 0, K, in_mask, T, N, K, tw, row0 * ldw + ctx.col_off, ldw, tb, row0)
             want_db = False
         elif need[1]:
-            dw = torch.zeros_like(w) if ldw > K else torch.empty_like(w)
-            db = _empty(N, like=x) if want_db else None
-            _wgrad_raw(hmx.ptr(g), N, hmx.ptr(x), K, in_mask, T, N, K, hmx.ptr(dw) + 4 * ctx.col_off, ldw, db, x.device)
+            whole = (row0, row1) == (0, n_all)
+            dw = torch.zeros(n_all, ldw, dtype=w.dtype, device=w.device) if (ldw > K or not whole) else torch.empty_like(w)
+            db_full = (torch.zeros(n_all, dtype=w.dtype, device=w.device) if not whole else _empty(N, like=x)) if want_db else None
+            _wgrad_raw(hmx.ptr(g), N, hmx.ptr(x), K, in_mask, T, N, K, hmx.ptr(dw) + 4 * (row0 * ldw + ctx.col_off), ldw,
+                       db_full[row0:row1] if db_full is not None else None, x.device)
+            db = db_full
             want_db = False
         if want_db:              # frozen weight, trainable bias: the bias gradient is the column sum of dy
             db = colsum(g)
+            if (row0, row1) != (0, n_all):
+                full = torch.zeros(n_all, dtype=db.dtype, device=db.device)
+                full[row0:row1] = db
+                db = full
         if need[5]:
             dr1 = g if ctx.c[0] == 1.0 else combine([g], [ctx.c[0]])
         if need[7]:
             dr2 = g if ctx.c[1] == 1.0 else combine([g], [ctx.c[1]])
-        return dx, dw, db, None, None, dr1, None, dr2, None, None
+        return dx, dw, db, None, None, dr1, None, dr2, None, None, None
 
 
-def linear(x, weight, bias=None, in_mask=None, out_mask=None, r1=None, c1=0.0, r2=None, c2=0.0, col_off=0):
+def linear(x, weight, bias=None, in_mask=None, out_mask=None, r1=None, c1=0.0, r2=None, c2=0.0, col_off=0, rows=None):
     """nn.Linear forward on bf16 MFMA; uses the x.shape[1] columns of `weight` that start at column `col_off`
-    (a column block of a wider projection: the other columns see no input and get a zero gradient)."""
-    return _Linear.apply(x, weight, bias, in_mask, out_mask, r1, float(c1), r2, float(c2), int(col_off))
+    (a column block of a wider projection: the other columns see no input and get a zero gradient).  rows = (r0, r1):
+    only output rows r0 .. r1 of `weight` / `bias` are used (the q or the k / v block of an attention in_proj): the
+    parameters are passed whole, so their gradients go straight into the full .grad instead of through slice views."""
+    return _Linear.apply(x, weight, bias, in_mask, out_mask, r1, float(c1), r2, float(c2), int(col_off),
+                         None if rows is None else (int(rows[0]), int(rows[1])))
 
 
 class _HeadsLinear(torch.autograd.Function):

@@ -254,8 +254,8 @@ class MultiScaleUserEncoder(nn.Module):
         ca = self.cross_attention
         H = ca.num_heads
         W, bias = ca.in_proj_weight, ca.in_proj_bias
-        q = E.linear(sf, W[:d], bias[:d])
-        kv = E.linear(long_.reshape(B * L, d), W[d:], bias[d:])
+        q = E.linear(sf, W, bias, rows=(0, d))
+        kv = E.linear(long_.reshape(B * L, d), W, bias, rows=(d, 3 * d))
         drop = None
         if self.training and ca.dropout > 0.0:
             drop = feature_ops.dropout_multiplier((B, H, L), ca.dropout, long_.device)

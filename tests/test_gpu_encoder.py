@@ -150,6 +150,36 @@ def test_heads_linear_one_launch_equals_per_head_launches(T, H, N, K, xs, ys):
                                   s) == -1          # HMX_EINVAL: more heads than one launch takes
 
 
+@pytest.mark.parametrize("direct", [False, True], ids=["autograd", "direct_param_grad"])
+def test_linear_on_a_row_range_of_the_parameters(direct):
+    """E.linear(x, W, b, rows=(r0, r1)) against fp32 matmuls on the sliced parameters: output, dx, and dW / db that are
+    zero outside the rows and right inside them, through autograd's returned gradients and through the direct
+    accumulation into .grad (two calls on disjoint row ranges of one parameter, as the attention in_proj does)."""
+    g = torch.Generator().manual_seed(11)
+    T, K, N = 300, 64, 192
+    x = torch.randn(T, K, generator=g)
+    W = torch.nn.Parameter((torch.randn(N, K, generator=g) / 8).to(DEV))
+    b = torch.nn.Parameter(torch.randn(N, generator=g).to(DEV))
+    xd = x.to(DEV).requires_grad_()
+    gy1, gy2 = torch.randn(T, 64, generator=g), torch.randn(T, 128, generator=g)
+    E.set_direct_param_grad(direct)
+    try:
+        y1 = E.linear(xd, W, b, rows=(0, 64))
+        y2 = E.linear(xd, W, b, rows=(64, 192))
+        (y1 * gy1.to(DEV)).sum().add((y2 * gy2.to(DEV)).sum()).backward()
+        E.flush_deferred_wgrads()
+    finally:
+        E.set_direct_param_grad(False)
+    Wr, br, xr = W.detach().cpu().clone().requires_grad_(), b.detach().cpu().clone().requires_grad_(), x.clone().requires_grad_()
+    r1, r2 = xr @ Wr[:64].t() + br[:64], xr @ Wr[64:].t() + br[64:]
+    ((r1 * gy1).sum() + (r2 * gy2).sum()).backward()
+    close(y1, r1, 1e-4, 1e-4, "rows 0..64")
+    close(y2, r2, 1e-4, 1e-4, "rows 64..192")
+    close(xd.grad, xr.grad, 1e-4, 1e-4, "dx")
+    close(W.grad, Wr.grad, 1e-3, 1e-3, "dW")
+    close(b.grad, br.grad, 1e-4, 1e-4, "db")
+
+
 def _wgrad_case(T, N, K, dy_off=0, x_off=0, pad=0, bias=True, mask=True, groups=None, accumulate=True, seed=0):
     """One descriptor on column-slice views (offsets / row padding in floats) and its float64 answer."""
     from generative_recommenders_amd import hmx
