@@ -185,6 +185,22 @@ class HydraBlock(_HydraBlockBase):
     first = False
 
 
+class _AddPerSequence(torch.autograd.Function):
+    """x (B, L, d) + c * v (B, d) broadcast over the positions (hydra3.py:547).  Backward: x's gradient is the incoming
+    one as it is, v's is c times its sum over the positions -- autograd's own rule first scales the whole (B, L, d)
+    gradient by c and then sums it."""
+
+    @staticmethod
+    def forward(ctx, x, v, c):
+        ctx.c = c
+        return torch.add(x, v.unsqueeze(1), alpha=c)
+
+    @staticmethod
+    def backward(ctx, g):
+        dv = g.sum(1).mul_(ctx.c) if ctx.needs_input_grad[1] else None
+        return (g if ctx.needs_input_grad[0] else None), dv, None
+
+
 class _ScaleWindows(torch.autograd.Function):
     """(sequence[:, -sw:], sequence[:, -mw:], sequence) for the three encoders of hydra3.py:528-530.  Through plain
     slicing the backward pass builds two zero-filled (B, L, d) tensors, copies a window into each and adds all three;
@@ -266,7 +282,7 @@ class MultiScaleUserEncoder(nn.Module):
         z = E.linear(lf, gate.weight, None, r1=z, c1=1.0, col_off=2 * d)
         mixed = feature_ops.gate_mix(z, att, lf)          # sigmoid(z) * att + (1 - sigmoid(z)) * lf
         fused = E.linear(E.rmsnorm(mixed, self.norm.scale, self.norm.eps), self.output_proj.weight, self.output_proj.bias)
-        return long_ + 0.5 * fused.view(B, 1, d)
+        return _AddPerSequence.apply(long_, fused, 0.5)
 
 
 class PositionAwareEncoder(nn.Module):
